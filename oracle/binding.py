@@ -1,0 +1,140 @@
+"""ctypes binding of oracle/libpbrs_oracle.so (see oracle/oracle_api.h). TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TRACE_MAX_BOUNCES = 16
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "closest_rays", "shadow_rays", "tlas_nodes", "blas_nodes", "instances", "instance_hits", "triangles", "spheres",
+        "quads", "cuboids", "disks", "tri_shading", "shade_events", "samples", "panics", "tlas_ties", "sphere_inside")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+HIT_DTYPE = np.dtype([("t", np.float32), ("inst", np.uint32), ("prim", np.uint32), ("b1", np.float32), ("b2", np.float32)])
+
+
+class BounceTrace(C.Structure):
+    _fields_ = [("hit", C.c_uint32), ("t", C.c_float), ("inst", C.c_uint32), ("prim", C.c_uint32), ("b1", C.c_float),
+                ("b2", C.c_float), ("pos", C.c_float * 3), ("normal", C.c_float * 3), ("radiance_after_nee", C.c_float * 3),
+                ("f", C.c_float * 3), ("wi", C.c_float * 3), ("pr", C.c_float), ("pr_is_mass", C.c_uint32),
+                ("beta_after", C.c_float * 3)]
+
+
+class PathTrace(C.Structure):
+    _fields_ = [("ray_o", C.c_float * 3), ("ray_d", C.c_float * 3), ("n_bounces", C.c_uint32),
+                ("bounce", BounceTrace * TRACE_MAX_BOUNCES), ("radiance", C.c_float * 3), ("panics", C.c_uint32)]
+
+
+def build():
+    """Compile the oracle with its Makefile (g++ -O2 -ffp-contract=off)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libpbrs_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.oracle_scene_build.restype = C.c_void_p
+        L.oracle_scene_build.argtypes = [C.c_void_p]
+        L.oracle_scene_free.argtypes = [C.c_void_p]
+        L.oracle_tlas_height.restype = C.c_uint32
+        L.oracle_tlas_height.argtypes = [C.c_void_p]
+        L.oracle_render_tile.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.oracle_trace_sample.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_uint64, C.c_void_p]
+        L.oracle_intersect_rays.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        L.oracle_camera_rays.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_void_p, C.c_void_p]
+        L.oracle_numeric_eval.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_rng_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_selftest.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32]
+        L.oracle_selftest_count.restype = C.c_uint32
+        L.oracle_selftest_name.restype = C.c_char_p
+        L.oracle_selftest_name.argtypes = [C.c_uint32]
+        _LIB = L
+    return _LIB
+
+
+NUMERIC_FNS = {"sin": 0, "cos": 1, "tan": 2, "atan": 3, "atan2": 4, "acos": 5, "exp": 6, "ln": 7, "hypot": 8, "div": 9,
+               "sqrt": 10, "asin": 11, "powi": 12, "fract": 13, "floor": 14}
+
+
+def numeric_eval(fn, x, y=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        yp = y.ctypes.data
+    rc = lib().oracle_numeric_eval(NUMERIC_FNS[fn], x.size, x.ctypes.data, yp, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def rng_stream(seed, pixel, sample, n):
+    out = np.empty(n, dtype=np.float32)
+    lib().oracle_rng_stream(seed, pixel, sample, n, out.ctypes.data)
+    return out
+
+
+class OracleScene:
+    def __init__(self, scene_builder):
+        self._sb = scene_builder
+        self._spec = scene_builder.build()
+        self.width = self._spec.camera.width
+        self.height = self._spec.camera.height
+        self._h = lib().oracle_scene_build(C.addressof(self._spec))
+
+    def close(self):
+        if self._h:
+            lib().oracle_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def tlas_height(self):
+        return lib().oracle_tlas_height(self._h)
+
+    def render(self, strata_x, strata_y, depth, seed, tile=None, nthreads=None):
+        x0, y0, w, h = tile or (0, 0, self.width, self.height)
+        out = np.empty((h, w, 3), dtype=np.float32)
+        st = Stats()
+        nthreads = nthreads or os.cpu_count() or 1
+        lib().oracle_render_tile(self._h, x0, y0, w, h, strata_x, strata_y, depth, seed, nthreads, out.ctypes.data, C.addressof(st))
+        return out, st.as_dict()
+
+    def trace_sample(self, row, col, sample, strata_x, strata_y, depth, seed):
+        tr = PathTrace()
+        lib().oracle_trace_sample(self._h, row, col, sample, strata_x, strata_y, depth, seed, C.addressof(tr))
+        return tr
+
+    def camera_rays(self, sample, strata_x, strata_y, seed, tile=None):
+        x0, y0, w, h = tile or (0, 0, self.width, self.height)
+        o = np.empty((h * w, 3), dtype=np.float32)
+        d = np.empty((h * w, 3), dtype=np.float32)
+        lib().oracle_camera_rays(self._h, x0, y0, w, h, sample, strata_x, strata_y, seed, o.ctypes.data, d.ctypes.data)
+        return o, d
+
+    def intersect(self, origins, dirs, tmax, closest=True, anyhit=True):
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+        tmax = np.ascontiguousarray(tmax, dtype=np.float32)
+        n = len(tmax)
+        hits = np.empty(n, dtype=HIT_DTYPE) if closest else None
+        occ = np.empty(n, dtype=np.uint8) if anyhit else None
+        st = Stats()
+        lib().oracle_intersect_rays(self._h, n, origins.ctypes.data, dirs.ctypes.data, tmax.ctypes.data,
+                                    hits.ctypes.data if closest else None, occ.ctypes.data if anyhit else None, C.addressof(st))
+        return hits, occ, st.as_dict()

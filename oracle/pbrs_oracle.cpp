@@ -1,0 +1,466 @@
+// oracle/pbrs_oracle.cpp — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of the reference's per-pixel Monte-Carlo path integrator:
+//   src/main.rs:192-231 (pixel/sample loop, row parallelism), src/pathintegrator.rs:9-74,
+//   src/directlighting.rs:58-232, scene/src/lib.rs.
+// plus the C entry points tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg bind to.
+// It is the checker for the HIP path, never the thing shipped: nothing under pbrs_amd/ links or
+// loads this library.
+//
+// PARITY PINNING: the Rust reference cannot be built here (no cargo/rustc, un-vendored crates,
+// SURVEY.md §8c).  The lower layers are pinned by transcribing every known-answer test the
+// reference holds for them (oracle/selftest.cpp); at integrator level (radiance per pixel, BVH
+// traversal, NEE) the reference has no tests and no golden images, so that level is
+// "parity unpinned": it rests on this restatement following the cited lines.
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+#include "oracle_api.h"
+#include "ref_scene.h"
+
+namespace ref {
+
+std::unique_ptr<Scene> scene_from_spec(const pbrs_scene_spec& spec) {
+    auto scene = std::make_unique<Scene>();
+    std::vector<std::shared_ptr<TriangleMesh>> meshes;
+    for (uint32_t m = 0; m < spec.n_meshes; ++m) meshes.push_back(std::shared_ptr<TriangleMesh>(mesh_from_soa(spec.meshes[m])));
+    std::vector<std::shared_ptr<Shape>> shapes;
+    for (uint32_t s = 0; s < spec.n_shapes; ++s) shapes.push_back(std::make_shared<Shape>(shape_from_spec(spec.shapes[s], meshes)));
+    std::vector<std::shared_ptr<Material>> mtls;
+    for (uint32_t m = 0; m < spec.n_materials; ++m) {
+        auto mt = std::make_shared<Material>();
+        mt->spec = spec.materials[m];
+        mtls.push_back(mt);
+    }
+    std::vector<std::unique_ptr<Instance>> instances;
+    for (uint32_t i = 0; i < spec.n_instances; ++i) {
+        auto inst = std::make_unique<Instance>();
+        inst->shape = shapes.at(spec.instances[i].shape);
+        inst->mtl = mtls.at(spec.instances[i].material);
+        std::memcpy(&inst->forward, spec.instances[i].forward, sizeof(Mat4));
+        std::memcpy(&inst->inverse, spec.instances[i].inverse, sizeof(Mat4));
+        inst->index = i;
+        instances.push_back(std::move(inst));
+    }
+    scene->tlas = build_bvh(std::move(instances));
+    for (uint32_t l = 0; l < spec.n_area_lights; ++l) {
+        const pbrs_area_light_spec& a = spec.area_lights[l];
+        DiffuseAreaLight light{};
+        light.emit_radiance = Color{a.emit[0], a.emit[1], a.emit[2]};
+        Shape sh = shape_from_spec(a.shape, meshes);
+        light.shape.kind = sh.kind;
+        light.shape.sphere = sh.sphere;
+        light.shape.disk = sh.disk;
+        light.shape.tri = sh.tri;
+        light.shape.quad = sh.quad;
+        light.area = light.shape.area();  // light/src/lib.rs:114-121
+        scene->area_lights.push_back(light);
+    }
+    for (uint32_t l = 0; l < spec.n_delta_lights; ++l) {
+        const pbrs_delta_light_spec& d = spec.delta_lights[l];
+        DeltaLight light{};
+        light.kind = d.kind;
+        light.v = Vec3{d.v[0], d.v[1], d.v[2]};
+        light.color = Color{d.color[0], d.color[1], d.color[2]};
+        light.world_radius = d.world_radius;
+        scene->delta_lights.push_back(light);
+    }
+    scene->env_constant = Color{spec.env_constant[0], spec.env_constant[1], spec.env_constant[2]};
+    scene->camera = camera_from_spec(spec.camera);
+    return scene;
+}
+
+// ---- src/directlighting.rs ----------------------------------------------------------------------------
+static float power_heuristic2(float nf, float f_pdf, float ng, float g_pdf) {  // :224-232 with BETA = 2
+    float f = nf * f_pdf;
+    float g = ng * g_pdf;
+    return pn_powi(f, 2) / (pn_powi(f, 2) + pn_powi(g, 2));
+}
+
+static bool scene_occludes(const Scene& scene, const Ray& r) {
+    REF_COUNT(shadow_rays);
+    return scene.tlas->occludes(r);
+}
+
+static Color estimate_direct_delta_light(const Interaction& hit, const Material& mtl, const DeltaLight& light, const Scene& scene) {  // :101-153
+    std::vector<BXDF> bxdfs = mtl.bxdfs_at(hit);
+    REF_ASSERT(!bxdfs.empty());
+    BSDF bsdf = bsdf_new_frame(hit);
+    bsdf.bxdfs = &bxdfs;
+    Color light_radiance;
+    Vec3 wi;
+    Prob light_pr{};
+    Ray vis;
+    light.sample_incident_radiance(hit, &light_radiance, &wi, &light_pr, &vis);
+    Color bsdf_value = bsdf.eval(hit.wo, wi) * pn_abs(dot(hit.normal, wi));
+    if (!light_pr.is_positive() || is_black(light_radiance) || is_black(bsdf_value)) return black();
+    float scatter_pdf = bsdf.pdf(hit.wo, wi);
+    if (scene_occludes(scene, vis)) return black();
+    float weight, pr;
+    if (light_pr.is_mass) {
+        weight = 1.0f;
+        pr = light_pr.v;
+    } else {
+        weight = power_heuristic2(1.0f, light_pr.v, 1.0f, scatter_pdf);
+        pr = light_pr.v;
+    }
+    return (bsdf_value * light_radiance) * weight * pn_weak_recip(pr);
+}
+
+static Color estimate_direct_area_light(const Interaction& hit, const Material& mtl, float su, float sv, const DiffuseAreaLight& light,
+                                        float lu, float lv, const Scene& scene) {  // :155-222
+    Color radiance_d = black();
+    std::vector<BXDF> bxdfs = mtl.bxdfs_at(hit);
+    BSDF bsdf = bsdf_new_frame(hit);
+    bsdf.bxdfs = &bxdfs;
+
+    Color light_radiance;
+    Vec3 wi;
+    Prob light_pr{};
+    Ray vis;
+    light.sample_incident_radiance(hit, lu, lv, &light_radiance, &wi, &light_pr, &vis);
+    REF_ASSERT(light_pr.is_density());
+    if (light_pr.is_positive() && !is_black(light_radiance)) {
+        float light_pdf = light_pr.density();
+        Color bsdf_value = bsdf.eval(hit.wo, wi) * pn_abs(dot(hit.normal, wi));
+        float scatter_pdf = bsdf.pdf(hit.wo, wi);
+        if (!is_black(bsdf_value) && scatter_pdf > 0.0f && !scene_occludes(scene, vis)) {
+            float weight = power_heuristic2(1.0f, light_pdf, 1.0f, scatter_pdf);
+            radiance_d = radiance_d + bsdf_value * light_radiance * weight * pn_weak_recip(light_pdf);
+        }
+    }
+    // by_bsdf (:198-220)
+    {
+        Color bsdf_value;
+        Vec3 wi2;
+        Prob bsdf_pr{};
+        bsdf.sample(hit.wo, su, sv, &bsdf_value, &wi2, &bsdf_pr);
+        bsdf_value = bsdf_value * pn_abs(dot(hit.normal, wi2));
+        if (!(is_black(bsdf_value) || !bsdf_pr.is_positive())) {
+            Color incident_radiance;
+            float light_pdf;
+            Ray vis2;
+            if (light.radiance_to(hit, wi2, &incident_radiance, &light_pdf, &vis2)) {
+                if (!(is_black(incident_radiance) || light_pdf <= 0.0f || scene_occludes(scene, vis2))) {
+                    float weight, pr;
+                    if (bsdf_pr.is_mass) {
+                        weight = 1.0f;
+                        pr = bsdf_pr.v;
+                    } else {
+                        weight = power_heuristic2(1.0f, bsdf_pr.v, 1.0f, light_pdf);
+                        pr = bsdf_pr.v;
+                    }
+                    Color f = bsdf_value * incident_radiance;
+                    radiance_d = radiance_d + weight * f * pn_weak_recip(pr);
+                }
+            }
+        }
+    }
+    return radiance_d;
+}
+
+static Color uniform_sample_one_light(const Interaction& hit, const Material& mtl, const Scene& scene, uint64_t* rng) {  // :58-99
+    size_t num_lights = scene.delta_lights.size() + scene.area_lights.size() + (scene.has_env_light() ? 1 : 0);
+    if (num_lights == 0) return black();
+    float light_pdf = 1.0f / (float)num_lights;
+    // RNG contract: gen_range(0..n) becomes min(floor(u*n), n-1).
+    float uidx = pn_rng_f32(rng);
+    size_t chosen_index = (size_t)(uidx * (float)num_lights);
+    if (chosen_index > num_lights - 1) chosen_index = num_lights - 1;
+    float lu = pn_rng_f32(rng), lv = pn_rng_f32(rng);
+    float su = pn_rng_f32(rng), sv = pn_rng_f32(rng);
+    Color one;
+    if (chosen_index < scene.delta_lights.size()) {
+        one = estimate_direct_delta_light(hit, mtl, scene.delta_lights[chosen_index], scene);
+    } else if (chosen_index >= scene.delta_lights.size() && chosen_index < scene.area_lights.size()) {  // Q6
+        one = estimate_direct_area_light(hit, mtl, su, sv, scene.area_lights[chosen_index - scene.delta_lights.size()], lu, lv, scene);
+    } else {  // :80-96
+        std::vector<BXDF> bxdfs = mtl.bxdfs_at(hit);
+        REF_ASSERT(!bxdfs.empty());
+        BSDF bsdf = bsdf_new_frame(hit);
+        bsdf.bxdfs = &bxdfs;
+        Color f;
+        Vec3 wi;
+        Prob pr{};
+        bsdf.sample(hit.wo, su, sv, &f, &wi, &pr);
+        Ray incident_ray = spawn_ray(hit, wi);
+        Color incident_radiance = scene_occludes(scene, incident_ray) ? black() : scene.eval_env_light(incident_ray);
+        one = incident_radiance * f * pn_abs(dot(wi, hit.normal)) * pn_weak_recip(pr.v);
+    }
+    return one * (1.0f / light_pdf);
+}
+
+// ---- src/pathintegrator.rs:9-74 --------------------------------------------------------------------------
+static Color path_integrator(const Scene& scene, Ray ray, int depth, uint64_t* rng, oracle_path_trace* trace) {
+    Color radiance = black();
+    bool specular_bounce = false;
+    Color beta = gray(1.0f);
+    if (trace) trace->n_bounces = 0;
+    for (int bounces = 0; bounces < depth; ++bounces) {
+        Hit h;
+        REF_COUNT(closest_rays);
+        bool has_hit = scene.tlas->intersect(ray, &h);
+        if (trace && bounces < ORACLE_TRACE_MAX_BOUNCES) {
+            oracle_bounce_trace& b = trace->bounce[bounces];
+            std::memset(&b, 0, sizeof(b));
+            b.hit = has_hit ? 1 : 0;
+            if (has_hit) {
+                b.t = h.isect.ray_t;
+                b.inst = h.inst->index;
+                b.prim = h.isect.prim;
+                b.b1 = h.isect.b1;
+                b.b2 = h.isect.b2;
+                b.pos[0] = h.isect.pos.x; b.pos[1] = h.isect.pos.y; b.pos[2] = h.isect.pos.z;
+                b.normal[0] = h.isect.normal.x; b.normal[1] = h.isect.normal.y; b.normal[2] = h.isect.normal.z;
+            }
+            trace->n_bounces = bounces + 1;
+        }
+        if (bounces == 0 || specular_bounce) {
+            Color e = has_hit ? h.inst->mtl->emission() : scene.eval_env_light(ray);
+            radiance = radiance + beta * e;
+        }
+        if (!has_hit) break;
+        REF_COUNT(shade_events);
+        const Interaction& hit = h.isect;
+        const Material& mtl = *h.inst->mtl;
+        std::vector<BXDF> bxdfs = mtl.bxdfs_at(hit);
+
+        radiance = radiance + beta * uniform_sample_one_light(hit, mtl, scene, rng);
+
+        BSDF shading_point = bsdf_new_frame(hit);
+        shading_point.bxdfs = &bxdfs;
+        float r0 = pn_rng_f32(rng), r1 = pn_rng_f32(rng);
+        Color f;
+        Vec3 wi;
+        Prob pr{};
+        shading_point.sample(-ray.dir, r0, r1, &f, &wi, &pr);
+        if (trace && bounces < ORACLE_TRACE_MAX_BOUNCES) {
+            oracle_bounce_trace& b = trace->bounce[bounces];
+            b.radiance_after_nee[0] = radiance.r; b.radiance_after_nee[1] = radiance.g; b.radiance_after_nee[2] = radiance.b;
+            b.f[0] = f.r; b.f[1] = f.g; b.f[2] = f.b;
+            b.wi[0] = wi.x; b.wi[1] = wi.y; b.wi[2] = wi.z;
+            b.pr = pr.v;
+            b.pr_is_mass = pr.is_mass;
+        }
+        if (is_black(f) || pr.is_zero()) break;
+        specular_bounce = pr.is_mass;
+        float p = pr.v;
+        beta = beta * f * dot(wi, hit.normal) * pn_recip(p);  // Q9: no abs
+        ray = spawn_ray(hit, wi);
+        if (bounces > 3) {
+            float q = pn_max(1.0f - luminance(beta), 0.05f);
+            if (pn_rng_f32(rng) < q) break;
+            beta = beta * pn_recip(1.0f - q);
+        }
+        if (trace && bounces < ORACLE_TRACE_MAX_BOUNCES) {
+            oracle_bounce_trace& b = trace->bounce[bounces];
+            b.beta_after[0] = beta.r; b.beta_after[1] = beta.g; b.beta_after[2] = beta.b;
+        }
+    }
+    return radiance;
+}
+
+}  // namespace ref
+
+// ===== C entry points ========================================================================================
+using namespace ref;
+
+struct oracle_scene {
+    std::unique_ptr<Scene> scene;
+    Diag build_diag;
+};
+
+extern "C" {
+
+oracle_scene* oracle_scene_build(const pbrs_scene_spec* spec) {
+    auto* s = new oracle_scene();
+    g_diag = &s->build_diag;
+    s->scene = scene_from_spec(*spec);
+    g_diag = nullptr;
+    return s;
+}
+void oracle_scene_free(oracle_scene* s) { delete s; }
+
+uint32_t oracle_tlas_height(const oracle_scene* s) { return s->scene->tlas->height(); }
+
+static void copy_counters(const Counters& c, const Diag& d, oracle_stats* out) {
+    if (!out) return;
+    out->closest_rays = c.closest_rays; out->shadow_rays = c.shadow_rays; out->tlas_nodes = c.tlas_nodes;
+    out->blas_nodes = c.blas_nodes; out->instances = c.instances; out->instance_hits = c.instance_hits;
+    out->triangles = c.triangles; out->spheres = c.spheres; out->quads = c.quads; out->cuboids = c.cuboids;
+    out->disks = c.disks; out->tri_shading = c.tri_shading; out->shade_events = c.shade_events; out->samples = c.samples;
+    out->panics = d.panics; out->tlas_ties = d.tlas_ties; out->sphere_inside = d.sphere_inside;
+}
+
+// src/main.rs:192-231 restricted to the tile [x0,x0+w) x [y0,y0+h); rows are dealt to `nthreads`
+// std::threads (rayon's into_par_iter over rows, :219-224).  strata_x = strata_y = msaa reproduces
+// the reference's `i / msaa`, `i % msaa` stratification (:197-201).
+int oracle_render_tile(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t strata_x, uint32_t strata_y,
+                       uint32_t max_depth, uint64_t seed, uint32_t nthreads, float* rgb_out, oracle_stats* stats_out) {
+    const Scene& scene = *os->scene;
+    if (nthreads == 0) nthreads = 1;
+    const uint32_t width = scene.camera.width;
+    const uint32_t spp = strata_x * strata_y;
+    std::atomic<uint32_t> next_row{0};
+    std::vector<Counters> cnts(nthreads);
+    std::vector<Diag> diags(nthreads);
+    auto worker = [&](uint32_t tid) {
+        g_cnt = &cnts[tid];
+        g_diag = &diags[tid];
+        for (;;) {
+            uint32_t ry = next_row.fetch_add(1);
+            if (ry >= h) break;
+            uint32_t row = y0 + ry;
+            for (uint32_t cx = 0; cx < w; ++cx) {
+                uint32_t col = x0 + cx;
+                Color color_sum = black();
+                for (uint32_t i = 0; i < spp; ++i) {
+                    uint64_t rng = pn_rng_init(seed, row * width + col, i);
+                    float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);
+                    float jx = ((float)(i / strata_y) + r0) / (float)strata_x;
+                    float jy = ((float)(i % strata_y) + r1) / (float)strata_y;
+                    Ray ray;
+                    scene.camera.shoot_ray(row, col, jx, jy, &ray);
+                    REF_COUNT(samples);
+                    color_sum = color_sum + path_integrator(scene, ray, (int)max_depth, &rng, nullptr);
+                }
+                Color color = color_sum * (1.0f / (float)spp);  // scale_down_by, color.rs:90-95
+                float* px = rgb_out + 3 * ((size_t)ry * w + cx);
+                px[0] = color.r;
+                px[1] = color.g;
+                px[2] = color.b;
+            }
+        }
+        g_cnt = nullptr;
+        g_diag = nullptr;
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : pool) t.join();
+    Counters total;
+    Diag dtotal;
+    for (uint32_t t = 0; t < nthreads; ++t) {
+        total.add(cnts[t]);
+        dtotal.panics += diags[t].panics;
+        dtotal.tlas_ties += diags[t].tlas_ties;
+        dtotal.sphere_inside += diags[t].sphere_inside;
+    }
+    copy_counters(total, dtotal, stats_out);
+    return 0;
+}
+
+// One camera sample with a per-bounce trace (hit record, radiance after NEE, sampled f / wi / pr, beta).
+int oracle_trace_sample(const oracle_scene* os, uint32_t row, uint32_t col, uint32_t sample_index, uint32_t strata_x, uint32_t strata_y,
+                        uint32_t max_depth, uint64_t seed, oracle_path_trace* trace) {
+    const Scene& scene = *os->scene;
+    Diag d;
+    g_diag = &d;
+    uint64_t rng = pn_rng_init(seed, row * scene.camera.width + col, sample_index);
+    float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);
+    float jx = ((float)(sample_index / strata_y) + r0) / (float)strata_x;
+    float jy = ((float)(sample_index % strata_y) + r1) / (float)strata_y;
+    Ray ray;
+    scene.camera.shoot_ray(row, col, jx, jy, &ray);
+    trace->ray_o[0] = ray.origin.x; trace->ray_o[1] = ray.origin.y; trace->ray_o[2] = ray.origin.z;
+    trace->ray_d[0] = ray.dir.x; trace->ray_d[1] = ray.dir.y; trace->ray_d[2] = ray.dir.z;
+    Color L = path_integrator(scene, ray, (int)max_depth, &rng, trace);
+    trace->radiance[0] = L.r; trace->radiance[1] = L.g; trace->radiance[2] = L.b;
+    trace->panics = (uint32_t)d.panics;
+    g_diag = nullptr;
+    return 0;
+}
+
+// Closest hit / any hit for caller-supplied rays (tlas/src/bvh.rs:77-113): the `extend` / `shadow`
+// kernel parity harness.  hits_out: n records of {t, inst, prim, b1, b2} (inst = 0xffffffff on a miss).
+int oracle_intersect_rays(const oracle_scene* os, uint32_t n, const float* origins, const float* dirs, const float* tmax,
+                          oracle_hit_record* hits_out, uint8_t* occluded_out, oracle_stats* stats_out) {
+    const Scene& scene = *os->scene;
+    Counters c;
+    Diag d;
+    g_cnt = &c;
+    g_diag = &d;
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r{Vec3{origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]}, Vec3{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]}, tmax[i]};
+        if (hits_out) {
+            Ray rm = r;
+            Hit h;
+            c.closest_rays++;
+            if (scene.tlas->intersect(rm, &h)) {
+                hits_out[i].t = h.isect.ray_t;
+                hits_out[i].inst = h.inst->index;
+                hits_out[i].prim = h.isect.prim;
+                hits_out[i].b1 = h.isect.b1;
+                hits_out[i].b2 = h.isect.b2;
+            } else {
+                hits_out[i].t = pn_inf();
+                hits_out[i].inst = 0xffffffffu;
+                hits_out[i].prim = 0;
+                hits_out[i].b1 = hits_out[i].b2 = 0.0f;
+            }
+        }
+        if (occluded_out) {
+            c.shadow_rays++;
+            occluded_out[i] = scene.tlas->occludes(r) ? 1 : 0;
+        }
+    }
+    copy_counters(c, d, stats_out);
+    g_cnt = nullptr;
+    g_diag = nullptr;
+    return 0;
+}
+
+// Camera rays exactly as src/main.rs:197-203 generates them (for raygen parity).
+int oracle_camera_rays(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t sample_index,
+                       uint32_t strata_x, uint32_t strata_y, uint64_t seed, float* origins, float* dirs) {
+    const Scene& scene = *os->scene;
+    for (uint32_t ry = 0; ry < h; ++ry)
+        for (uint32_t cx = 0; cx < w; ++cx) {
+            uint32_t row = y0 + ry, col = x0 + cx;
+            uint64_t rng = pn_rng_init(seed, row * scene.camera.width + col, sample_index);
+            float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);
+            float jx = ((float)(sample_index / strata_y) + r0) / (float)strata_x;
+            float jy = ((float)(sample_index % strata_y) + r1) / (float)strata_y;
+            Ray ray;
+            scene.camera.shoot_ray(row, col, jx, jy, &ray);
+            size_t k = (size_t)ry * w + cx;
+            origins[3 * k] = ray.origin.x; origins[3 * k + 1] = ray.origin.y; origins[3 * k + 2] = ray.origin.z;
+            dirs[3 * k] = ray.dir.x; dirs[3 * k + 1] = ray.dir.y; dirs[3 * k + 2] = ray.dir.z;
+        }
+    return 0;
+}
+
+// The f32 numeric contract, for ulp checks against libm and bitwise checks against gfx950.
+int oracle_numeric_eval(uint32_t fn, uint32_t n, const float* x, const float* y, float* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        float a = x[i], b = y ? y[i] : 0.0f, r;
+        switch (fn) {
+            case 0: r = pn_sin(a); break;
+            case 1: r = pn_cos(a); break;
+            case 2: r = pn_tan(a); break;
+            case 3: r = pn_atan(a); break;
+            case 4: r = pn_atan2(a, b); break;
+            case 5: r = pn_acos(a); break;
+            case 6: r = pn_exp(a); break;
+            case 7: r = pn_ln(a); break;
+            case 8: r = pn_hypot(a, b); break;
+            case 9: r = a / b; break;
+            case 10: r = pn_sqrt(a); break;
+            case 11: r = pn_asin(a); break;
+            case 12: r = pn_powi(a, (int)b); break;
+            case 13: r = pn_fract(a); break;
+            case 14: r = pn_floor(a); break;
+            default: return -1;
+        }
+        out[i] = r;
+    }
+    return 0;
+}
+int oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out) {
+    uint64_t s = pn_rng_init(seed, pixel, sample);
+    for (uint32_t i = 0; i < n; ++i) out[i] = pn_rng_f32(&s);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,294 @@
+"""ctypes mirror of include/pbrs_scene_spec.h plus a small builder.
+
+The spec is the plain-data form of what the reference's scene/src/preset.rs hands to
+`tlas::build_bvh` and `Scene::new(..).with_lights(..)`: instances of
+(shape, material, transform), area/delta lights, a constant environment colour and the camera.
+It carries no acceleration structure; the host flattener (pbrs_amd/csrc/host) builds that.
+"""
+import ctypes as C
+
+import numpy as np
+
+SHAPE_SPHERE, SHAPE_QUAD, SHAPE_CUBOID, SHAPE_DISK, SHAPE_TRIANGLE, SHAPE_MESH = range(6)
+(MTL_LAMBERTIAN, MTL_METAL, MTL_GLOSSY, MTL_MIRROR, MTL_PLASTIC, MTL_DIELECTRIC, MTL_DIFFUSE_LIGHT, MTL_UBER,
+ MTL_SUBSTRATE) = range(9)
+MTL_FLAG_REMAP_ROUGHNESS, MTL_FLAG_HAS_KR, MTL_FLAG_HAS_KT = 1, 2, 4
+DELTA_POINT, DELTA_DISTANT = 0, 1
+
+f32 = np.float32
+
+
+class ShapeSpec(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("mesh", C.c_uint32), ("p", C.c_float * 9)]
+
+
+class MeshSpec(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32), ("positions", C.POINTER(C.c_float)),
+                ("normals", C.POINTER(C.c_float)), ("uvs", C.POINTER(C.c_float)), ("indices", C.POINTER(C.c_uint32))]
+
+
+class MaterialSpec(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("flags", C.c_uint32), ("p", C.c_float * 16)]
+
+
+class InstanceSpec(C.Structure):
+    _fields_ = [("shape", C.c_uint32), ("material", C.c_uint32), ("forward", C.c_float * 16), ("inverse", C.c_float * 16)]
+
+
+class AreaLightSpec(C.Structure):
+    _fields_ = [("emit", C.c_float * 3), ("shape", ShapeSpec)]
+
+
+class DeltaLightSpec(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("v", C.c_float * 3), ("color", C.c_float * 3), ("world_radius", C.c_float)]
+
+
+class CameraSpec(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("fov_y_rad", C.c_float), ("from_", C.c_float * 3),
+                ("target", C.c_float * 3), ("up", C.c_float * 3)]
+
+
+class SceneSpec(C.Structure):
+    _fields_ = [("n_meshes", C.c_uint32), ("meshes", C.POINTER(MeshSpec)),
+                ("n_shapes", C.c_uint32), ("shapes", C.POINTER(ShapeSpec)),
+                ("n_materials", C.c_uint32), ("materials", C.POINTER(MaterialSpec)),
+                ("n_instances", C.c_uint32), ("instances", C.POINTER(InstanceSpec)),
+                ("n_area_lights", C.c_uint32), ("area_lights", C.POINTER(AreaLightSpec)),
+                ("n_delta_lights", C.c_uint32), ("delta_lights", C.POINTER(DeltaLightSpec)),
+                ("env_constant", C.c_float * 3), ("camera", CameraSpec)]
+
+
+# ---- AffineTransform (geometry/src/transform.rs:133-194) in f32, column-major Mat4 -----------------
+
+def _mat4_mul(a, b):
+    """math/src/hcm.rs:546-556: column c of the product is a * b.cols[c]; sums run left to right in f32."""
+    out = np.zeros((4, 4), dtype=f32)  # out[col][row]
+    for c in range(4):
+        acc = (a[0] * b[c][0]).astype(f32)
+        for k in range(1, 4):
+            acc = (acc + (a[k] * b[c][k]).astype(f32)).astype(f32)
+        out[c] = acc
+    return out
+
+
+class Transform:
+    """AffineTransform{forward, inverse}; matrices indexed [col][row] like glam's Mat4.cols."""
+
+    def __init__(self, forward=None, inverse=None):
+        self.forward = np.eye(4, dtype=f32) if forward is None else forward.astype(f32)
+        self.inverse = np.eye(4, dtype=f32) if inverse is None else inverse.astype(f32)
+
+    @staticmethod
+    def translater(t):  # transform.rs:140-145
+        fwd = np.eye(4, dtype=f32)
+        inv = np.eye(4, dtype=f32)
+        fwd[3, :3] = np.asarray(t, dtype=f32)
+        inv[3, :3] = -np.asarray(t, dtype=f32)
+        return Transform(fwd, inv)
+
+    @staticmethod
+    def rotater(axis, angle_rad):  # transform.rs:146-152, hcm.rs:508-520
+        axis = np.asarray(axis, dtype=f32)
+        s, c = f32(np.sin(f32(angle_rad))), f32(np.cos(f32(angle_rad)))
+        fwd = np.eye(4, dtype=f32)
+        ahat = (axis / f32(np.sqrt(f32(np.dot(axis, axis))))).astype(f32)
+        for i in range(3):
+            base = np.zeros(3, dtype=f32)
+            base[i] = 1.0
+            vc = (f32(np.dot(base, axis)) * axis / f32(np.dot(axis, axis))).astype(f32)
+            v1 = (base - vc).astype(f32)
+            v2 = np.cross(v1, ahat).astype(f32)
+            fwd[i, :3] = (vc + v1 * c + v2 * s).astype(f32)
+        return Transform(fwd, fwd.T.copy())
+
+    def __matmul__(self, rhs):  # transform.rs:185-194: self * rhs
+        return Transform(_mat4_mul(self.forward, rhs.forward), _mat4_mul(rhs.inverse, self.inverse))
+
+    def translate(self, t):  # :169-171  Translate(t) * self
+        return Transform.translater(t) @ self
+
+    def rotate_y(self, angle_rad):  # :177-179
+        return Transform.rotater([0, 1, 0], angle_rad) @ self
+
+    def rotate_x(self, angle_rad):
+        return Transform.rotater([1, 0, 0], angle_rad) @ self
+
+    def rotate_z(self, angle_rad):
+        return Transform.rotater([0, 0, 1], angle_rad) @ self
+
+
+def deg(d):
+    """f32::to_radians (math/src/float.rs:239-243)."""
+    return f32(f32(d) * f32(np.pi / 180.0))
+
+
+class SceneBuilder:
+    """Collects numpy-backed arrays and emits a SceneSpec whose pointers stay valid while the
+    builder is alive."""
+
+    def __init__(self):
+        self.meshes = []  # (positions, normals, uvs, indices)
+        self.shapes = []
+        self.materials = []
+        self.instances = []
+        self.area_lights = []
+        self.delta_lights = []
+        self.env = (0.0, 0.0, 0.0)
+        self.camera = None
+        self._keep = []
+
+    # -- shapes
+    def _shape(self, kind, p=(), mesh=0):
+        s = ShapeSpec()
+        s.kind, s.mesh = kind, mesh
+        for i, v in enumerate(p):
+            s.p[i] = float(f32(v))
+        return s
+
+    def add_shape(self, s):
+        self.shapes.append(s)
+        return len(self.shapes) - 1
+
+    def sphere(self, center, radius):
+        return self._shape(SHAPE_SPHERE, list(center) + [radius])
+
+    def quad(self, origin, side_u, side_v):
+        return self._shape(SHAPE_QUAD, list(origin) + list(side_u) + list(side_v))
+
+    def cuboid(self, p0, p1):
+        return self._shape(SHAPE_CUBOID, list(p0) + list(p1))
+
+    def disk(self, center, normal, radial):
+        return self._shape(SHAPE_DISK, list(center) + list(normal) + list(radial))
+
+    def triangle(self, p0, p1, p2):
+        return self._shape(SHAPE_TRIANGLE, list(p0) + list(p1) + list(p2))
+
+    def mesh(self, positions, normals, uvs, indices):
+        positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
+        normals = np.ascontiguousarray(normals, dtype=f32).reshape(-1, 3)
+        uvs = np.ascontiguousarray(uvs, dtype=f32).reshape(-1, 2)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        assert len(positions) == len(normals) == len(uvs)
+        assert indices.max() < len(positions)
+        self.meshes.append((positions, normals, uvs, indices))
+        return self._shape(SHAPE_MESH, mesh=len(self.meshes) - 1)
+
+    # -- materials
+    def material(self, kind, p, flags=0):
+        m = MaterialSpec()
+        m.kind, m.flags = kind, flags
+        for i, v in enumerate(p):
+            m.p[i] = float(f32(v))
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def lambertian(self, albedo):
+        return self.material(MTL_LAMBERTIAN, albedo)
+
+    def metal(self, eta, k, fuzziness):
+        return self.material(MTL_METAL, list(eta) + list(k) + [fuzziness])
+
+    def glossy(self, albedo, roughness):
+        return self.material(MTL_GLOSSY, list(albedo) + [roughness])
+
+    def mirror(self, albedo):
+        return self.material(MTL_MIRROR, albedo)
+
+    def plastic(self, diffuse, specular, roughness, remap_roughness=True):
+        return self.material(MTL_PLASTIC, list(diffuse) + list(specular) + [roughness],
+                             MTL_FLAG_REMAP_ROUGHNESS if remap_roughness else 0)
+
+    def dielectric(self, ior, reflect=(1, 1, 1), transmit=(1, 1, 1)):
+        return self.material(MTL_DIELECTRIC, [ior] + list(reflect) + list(transmit))
+
+    def diffuse_light(self, emit):
+        return self.material(MTL_DIFFUSE_LIGHT, emit)
+
+    def uber(self, kd, ks, kr=None, kt=None, rough=(0.1, 0.1), eta=1.5, opacity=1.0, remap_roughness=True):
+        flags = (MTL_FLAG_REMAP_ROUGHNESS if remap_roughness else 0) | (MTL_FLAG_HAS_KR if kr is not None else 0) | (
+            MTL_FLAG_HAS_KT if kt is not None else 0)
+        p = list(kd) + list(ks) + list(kr or (0, 0, 0)) + list(kt or (0, 0, 0)) + list(rough) + [eta, opacity]
+        return self.material(MTL_UBER, p, flags)
+
+    def substrate(self, kd, ks):
+        return self.material(MTL_SUBSTRATE, list(kd) + list(ks))
+
+    # -- instances / lights / camera
+    def instance(self, shape, material, transform=None):
+        """`shape` is a ShapeSpec (added) or an existing shape index."""
+        sid = shape if isinstance(shape, int) else self.add_shape(shape)
+        t = transform or Transform()
+        inst = InstanceSpec()
+        inst.shape, inst.material = sid, material
+        for c in range(4):
+            for r in range(4):
+                inst.forward[4 * c + r] = float(t.forward[c][r])
+                inst.inverse[4 * c + r] = float(t.inverse[c][r])
+        self.instances.append(inst)
+        return len(self.instances) - 1
+
+    def area_light(self, emit, shape):
+        a = AreaLightSpec()
+        for i in range(3):
+            a.emit[i] = float(f32(emit[i]))
+        a.shape = shape
+        self.area_lights.append(a)
+
+    def point_light(self, position, intensity):
+        d = DeltaLightSpec()
+        d.kind = DELTA_POINT
+        for i in range(3):
+            d.v[i] = float(f32(position[i]))
+            d.color[i] = float(f32(intensity[i]))
+        d.world_radius = 0.0
+        self.delta_lights.append(d)
+
+    def distant_light(self, casting_dir, radiance, world_radius):
+        d = DeltaLightSpec()
+        d.kind = DELTA_DISTANT
+        for i in range(3):
+            d.v[i] = float(f32(casting_dir[i]))
+            d.color[i] = float(f32(radiance[i]))
+        d.world_radius = float(f32(world_radius))
+        self.delta_lights.append(d)
+
+    def set_camera(self, width, height, fov_y_rad, from_, target, up=(0, 1, 0)):
+        cam = CameraSpec()
+        cam.width, cam.height, cam.fov_y_rad = width, height, float(f32(fov_y_rad))
+        for i in range(3):
+            cam.from_[i] = float(f32(from_[i]))
+            cam.target[i] = float(f32(target[i]))
+            cam.up[i] = float(f32(up[i]))
+        self.camera = cam
+
+    def build(self):
+        spec = SceneSpec()
+
+        def arr(items, ctype):
+            a = (ctype * max(len(items), 1))()
+            for i, it in enumerate(items):
+                a[i] = it
+            self._keep.append(a)
+            return a
+
+        mesh_structs = []
+        for (pos, nrm, uv, idx) in self.meshes:
+            m = MeshSpec()
+            m.n_vertices, m.n_triangles = len(pos), len(idx)
+            m.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
+            m.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))
+            m.uvs = uv.ctypes.data_as(C.POINTER(C.c_float))
+            m.indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+            mesh_structs.append(m)
+        spec.n_meshes, spec.meshes = len(mesh_structs), arr(mesh_structs, MeshSpec)
+        spec.n_shapes, spec.shapes = len(self.shapes), arr(self.shapes, ShapeSpec)
+        spec.n_materials, spec.materials = len(self.materials), arr(self.materials, MaterialSpec)
+        spec.n_instances, spec.instances = len(self.instances), arr(self.instances, InstanceSpec)
+        spec.n_area_lights, spec.area_lights = len(self.area_lights), arr(self.area_lights, AreaLightSpec)
+        spec.n_delta_lights, spec.delta_lights = len(self.delta_lights), arr(self.delta_lights, DeltaLightSpec)
+        for i in range(3):
+            spec.env_constant[i] = float(f32(self.env[i]))
+        assert self.camera is not None, "camera not set"
+        spec.camera = self.camera
+        return spec
