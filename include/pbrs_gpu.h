@@ -1,0 +1,248 @@
+/* pbrs_gpu.h — C ABI of the MI355X wavefront path tracer (libpbrs_gpu.so).
+ *
+ * What it replaces.  The reference has no FFI or plugin interface; its only seam on this path is
+ * the integrator function pointer `fn(&Scene, ray::Ray, i32) -> Color` chosen at
+ * src/main.rs:160-163 and called once per camera sample from the row loop at src/main.rs:192-213,
+ * which rayon runs over rows at :219-224.  A per-ray seam cannot feed a GPU, so this ABI lifts it to
+ * a per-tile batch seam that replaces src/main.rs:192-231 as a whole:
+ *     (scene, camera, strata, depth) -> row-major RGB f32
+ * with the same semantics (stratified jitter :197-201, `shoot_ray` :203, sequential f32 sum over
+ * samples :205, `scale_down_by` :208).  Each entry point below cites the reference lines it stands
+ * for.  INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * Conventions: POD structs, little-endian, plain pointers + counts, no ownership transfer
+ * (`pbrs_upload_scene` copies; the caller keeps its buffers).  Never unwinds or aborts: every call
+ * returns 0 or a negative PBRS_E_* and `pbrs_last_error` explains.  The reference's error model is
+ * panic; conditions that would panic there are counted in
+ * `pbrs_stats.invalid_samples` and the sample proceeds with the arithmetic result.
+ * Threading: one `pbrs_ctx` per GPU; different contexts may be driven concurrently from different
+ * host threads/processes; a single context is not re-entrant.
+ *
+ * The flattened scene (`pbrs_scene_desc`) is produced by the host side of the boundary — in the
+ * reference's own language that is scene/ + tlas/ + shape/ (Rust); here pbrs_amd/csrc/host
+ * (C++, include/pbrs_host.h) — by running `tlas::build_bvh` (tlas/src/bvh.rs:116-152) and
+ * `recursive_build` (shape/src/blas.rs:333-420) and linearising the trees.
+ */
+#ifndef PBRS_GPU_H
+#define PBRS_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBRS_OK 0
+#define PBRS_E_INVALID (-1)   /* bad argument / inconsistent scene description */
+#define PBRS_E_DEVICE (-2)    /* HIP runtime error (message in pbrs_last_error) */
+#define PBRS_E_NO_SCENE (-3)  /* render called before pbrs_upload_scene */
+#define PBRS_E_LIMIT (-4)     /* traversal stack deeper than the LDS budget, tile too large, ... */
+
+#define PBRS_LEAF_FLAG 0x80000000u
+
+/* A BVH node, 32 B, pre-order: the left child of node i is node i+1.
+ *   inner: a = index of the right child, b = split axis (BLAS; 0 for TLAS)
+ *   leaf : b = PBRS_LEAF_FLAG | count;  a = first triangle (BLAS, count <= n) or instance (TLAS, count = 1)
+ * bbox as in geometry/src/bvh.rs:11-14.  TLAS: tlas/src/bvh.rs:11-18.  BLAS: shape/src/blas.rs:10-18. */
+typedef struct pbrs_node {
+    float min[3];
+    uint32_t a;
+    float max[3];
+    uint32_t b;
+} pbrs_node;
+
+/* tlas/src/instance.rs:12-16.  Rows of the two affine Mat4 of geometry/src/transform.rs:16-19:
+ * row r = (cols[0][r], cols[1][r], cols[2][r], cols[3][r]); the fourth row is (0,0,0,1). */
+typedef struct pbrs_instance {
+    float inv[3][4];
+    float fwd[3][4];
+    uint32_t shape_kind;  /* enum pbrs_shape_kind (pbrs_scene_spec.h) */
+    uint32_t shape_index; /* analytic: index into shapes[]; mesh: index into meshes[] */
+    uint32_t material;
+    uint32_t pad;
+} pbrs_instance;
+
+/* Analytic shape parameters, 12 floats (shape/src/simple.rs:10-196), laid out as in pbrs_shape_spec.p;
+ * cuboid min/max already ordered (Cuboid::from_points), disk normal already unit (Disk::new). */
+typedef struct pbrs_shape {
+    float p[12];
+} pbrs_shape;
+
+typedef struct pbrs_mesh {
+    uint32_t root;       /* index of the BLAS root in blas_nodes[] */
+    uint32_t n_nodes;
+    uint32_t first_tri;  /* first triangle of this mesh in tri_verts[] / tri_shade[] */
+    uint32_t n_tris;
+    uint32_t height;     /* IsoBvhNode::height(), shape/src/blas.rs:21-26 */
+    uint32_t pad[3];
+} pbrs_mesh;
+
+/* One triangle's geometry in BLAS leaf order, Q11 swap applied: `let (i,k,j) = index_triple`
+ * (shape/src/blas.rs:162) => p0 = positions[i], p1 = positions[j], p2 = positions[k]. */
+typedef struct pbrs_tri_verts {
+    float p0[3];
+    uint32_t orig; /* index of the triangle in the input index buffer */
+    float p1[3];
+    float pad1;
+    float p2[3];
+    float pad2;
+} pbrs_tri_verts;
+
+/* Shading attributes of the same triangle, same vertex order (shape/src/blas.rs:170-185). */
+typedef struct pbrs_tri_shade {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    float pad;
+} pbrs_tri_shade;
+
+/* geometry/src/bxdf.rs:263-269 flattened (textures are Solid, so `bxdfs_at` is constant per material). */
+enum pbrs_bxdf_kind { PBRS_BXDF_SPECULAR = 0, PBRS_BXDF_DIFFUSE = 1, PBRS_BXDF_MICROFACET = 2 };
+enum pbrs_intrusion { PBRS_REFLECTION = 0, PBRS_TRANSMISSION = 1, PBRS_HYBRID = 2 };        /* bxdf.rs:35-40  */
+enum pbrs_fresnel_kind { PBRS_FRESNEL_NOP = 0, PBRS_FRESNEL_DIELECTRIC = 1, PBRS_FRESNEL_CONDUCTOR = 2 }; /* :284-289 */
+typedef struct pbrs_bxdf {
+    uint32_t kind;
+    uint32_t intrusion;   /* Specular only */
+    uint32_t fresnel;     /* Specular, Microfacet */
+    uint32_t oren_nayar;  /* Diffuse: 0 Lambertian, 1 Oren-Nayar */
+    float albedo[3];
+    float alpha_x;        /* Beckmann (microfacet.rs:11); already through roughness_to_alpha */
+    float eta[3];         /* dielectric: eta_front, eta_back, -; conductor: eta_t rgb (eta_i = 1) */
+    float alpha_y;
+    float k[3];           /* conductor k rgb; Oren-Nayar: coeff_a, coeff_b, - */
+    float pad;
+} pbrs_bxdf;
+
+#define PBRS_MAX_BXDFS 5 /* Uber, material/src/lib.rs:317-365 */
+typedef struct pbrs_material {
+    float emission[3]; /* Material::emission, material/src/lib.rs:24-26, :294-296 */
+    uint32_t n_bxdfs;
+    uint32_t first_bxdf;
+    uint32_t pad[3];
+} pbrs_material;
+
+/* light/src/lib.rs:107-111 + light/src/sample_shape.rs:38-43 (world-space shape, area precomputed). */
+typedef struct pbrs_area_light {
+    float emit[3];
+    uint32_t shape_kind;
+    float p[9];
+    float area;
+    float pad[2];
+} pbrs_area_light;
+
+/* light/src/lib.rs:29-39 */
+typedef struct pbrs_delta_light {
+    uint32_t kind;
+    float v[3];
+    float color[3];
+    float world_radius;
+} pbrs_delta_light;
+
+typedef struct pbrs_scene_desc {
+    uint32_t n_tlas_nodes;
+    const pbrs_node* tlas_nodes;
+    uint32_t tlas_height; /* BvhNode::height(), tlas/src/bvh.rs:56-61 */
+    uint32_t n_instances;
+    const pbrs_instance* instances;
+    uint32_t n_shapes;
+    const pbrs_shape* shapes;
+    uint32_t n_meshes;
+    const pbrs_mesh* meshes;
+    uint32_t n_blas_nodes;
+    const pbrs_node* blas_nodes;
+    uint32_t n_triangles;
+    const pbrs_tri_verts* tri_verts;
+    const pbrs_tri_shade* tri_shade;
+    uint32_t n_materials;
+    const pbrs_material* materials;
+    uint32_t n_bxdfs;
+    const pbrs_bxdf* bxdfs;
+    uint32_t n_area_lights;
+    const pbrs_area_light* area_lights;
+    uint32_t n_delta_lights;
+    const pbrs_delta_light* delta_lights;
+    float env_constant[3]; /* EnvLight::Constant, scene/src/lib.rs:12-16 */
+    uint32_t pad;
+} pbrs_scene_desc;
+
+/* geometry/src/camera.rs:9-17 with the three `orientation * {c,a,b}` products of shoot_ray (:68-70)
+ * hoisted: they do not depend on the pixel. */
+typedef struct pbrs_camera {
+    float center[3];
+    uint32_t width;
+    float c[3]; /* orientation * c */
+    uint32_t height;
+    float a[3]; /* orientation * a */
+    float pad0;
+    float b[3]; /* orientation * b */
+    float pad1;
+} pbrs_camera;
+
+/* Work counters in the units of SURVEY.md §8(d); filled only when `collect_counters` is set
+ * (an instrumented kernel variant runs; the timed variant carries no counters). */
+typedef struct pbrs_stats {
+    uint64_t samples;       /* camera samples rendered                                  */
+    uint64_t closest_rays;  /* BvhNode::intersect equivalents (tlas/src/bvh.rs:77)       */
+    uint64_t shadow_rays;   /* BvhNode::occludes equivalents  (tlas/src/bvh.rs:105)      */
+    uint64_t shade_events;  /* path vertices shaded                                      */
+    uint64_t tlas_nodes, blas_nodes, instances, instance_hits, triangles, tri_shading;
+    uint64_t spheres, quads, cuboids, disks;
+    uint64_t shadow_tlas_nodes, shadow_blas_nodes, shadow_instances, shadow_triangles, shadow_prims;
+    uint64_t invalid_samples; /* reference assert!/panic! conditions reached on device */
+    /* HIP-event time per stage, summed over launches, in ms, on the context's stream */
+    float ms_raygen, ms_extend, ms_shade, ms_shadow, ms_accumulate, ms_total;
+    uint32_t launches_extend, launches_shadow, launches_shade, passes;
+} pbrs_stats;
+
+typedef struct pbrs_ctx pbrs_ctx;
+
+/* One context per device.  Stands for the per-thread state of the rayon row loop (src/main.rs:219-224). */
+int pbrs_create(int device_ordinal, pbrs_ctx** out);
+void pbrs_destroy(pbrs_ctx*);
+const char* pbrs_last_error(const pbrs_ctx*);
+/* Run the pipeline on an existing HIP stream (e.g. torch's current stream); NULL = the context's own. */
+int pbrs_set_stream(pbrs_ctx*, void* hip_stream);
+
+/* Copies the flattened scene into HBM.  Stands for building `Scene` (scene/src/lib.rs:36-63). */
+int pbrs_upload_scene(pbrs_ctx*, const pbrs_scene_desc*);
+
+typedef struct pbrs_render_params {
+    uint32_t x0, y0, w, h;         /* tile, in pixels of the camera film                           */
+    uint32_t strata_x, strata_y;   /* spp = strata_x * strata_y; the reference has both = msaa    */
+    uint32_t max_depth;            /* `for bounces in 0..depth`, src/pathintegrator.rs:14          */
+    uint32_t samples_per_pass;     /* sample indices traced concurrently per pixel (0 = auto)      */
+    uint64_t seed;                 /* RNG contract, include/pbrs_numeric.h                          */
+    uint32_t collect_counters;     /* run the instrumented kernels and fill the work counters      */
+    uint32_t time_stages;          /* bracket every launch with HIP events and fill ms_*           */
+} pbrs_render_params;
+
+/* Renders a tile; replaces src/main.rs:192-231 for the rows/cols of the tile.  `rgb_out` is
+ * w*h*3 floats, row-major.  _host writes to caller-owned host memory (one D2H copy at the end);
+ * _device leaves the result in caller-owned device memory and does not synchronise the stream. */
+int pbrs_render_tile(pbrs_ctx*, const pbrs_camera*, const pbrs_render_params*, float* rgb_out_host, pbrs_stats* stats_out);
+int pbrs_render_tile_device(pbrs_ctx*, const pbrs_camera*, const pbrs_render_params*, float* rgb_out_device, pbrs_stats* stats_out);
+/* After a _device render with time_stages/collect_counters: waits for the stream and fills the stats. */
+int pbrs_collect_stats(pbrs_ctx*, pbrs_stats* stats_out);
+
+/* ---- parity-harness entry points (the reference's own functions, batched) -------------------------- */
+typedef struct pbrs_hit_record {
+    float t;
+    uint32_t inst; /* 0xffffffff = miss */
+    uint32_t prim;
+    float b1, b2;
+} pbrs_hit_record;
+/* `scene.tlas.intersect(&mut ray)` (tlas/src/bvh.rs:77-103) / `scene.tlas.occludes(&ray)` (:105-113)
+ * for n caller-supplied rays (host pointers; origins/dirs are n*3 floats). Either output may be NULL. */
+int pbrs_intersect_rays(pbrs_ctx*, uint32_t n, const float* origins, const float* dirs, const float* tmax,
+                        pbrs_hit_record* hits_out, uint8_t* occluded_out);
+/* Camera rays of one sample index for a tile (src/main.rs:197-203, geometry/src/camera.rs:65-77). */
+int pbrs_camera_rays(pbrs_ctx*, const pbrs_camera*, const pbrs_render_params*, uint32_t sample_index, float* origins_out,
+                     float* dirs_out);
+/* include/pbrs_numeric.h evaluated on the device (fn ids as oracle_numeric_eval). */
+int pbrs_numeric_eval(pbrs_ctx*, uint32_t fn, uint32_t n, const float* x, const float* y, float* out);
+/* Per-sample radiance of one sample index for a tile (before the sum over samples), for bisecting. */
+int pbrs_render_sample_radiance(pbrs_ctx*, const pbrs_camera*, const pbrs_render_params*, uint32_t sample_index, float* rgb_out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -422,8 +422,12 @@ bool TriangleMesh::intersect_one_pred(const MeshTriangle& tri, const Ray& r) con
 
 // blas.rs:422-476
 static bool intersect_bvh(const TriangleMesh& mesh, const IsoBvhNode* tree, const Ray& r, Interaction* out) {
-    REF_COUNT(blas_nodes);
-    if (!bbox_intersect(tree->bbox, r)) return false;
+    // :428 tests the root box, then the loop pops the root and tests it again with the same ray (:441):
+    // one box test as far as the work counters go (the second has the same operands and result).
+    if (!bbox_intersect(tree->bbox, r)) {
+        REF_COUNT(blas_nodes);
+        return false;
+    }
     std::vector<const IsoBvhNode*> node_stack;
     node_stack.reserve(60);
     node_stack.push_back(tree);

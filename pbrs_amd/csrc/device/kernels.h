@@ -1,0 +1,430 @@
+// device/kernels.h — the wavefront stages.
+//
+//   raygen      src/main.rs:197-203 + geometry/src/camera.rs:65-77
+//   extend      tlas/src/bvh.rs:77-103 (closest hit)            -> hit record per path
+//   shade       src/pathintegrator.rs:19-71 + src/directlighting.rs:58-222 minus the occlusion calls
+//   shadow      tlas/src/bvh.rs:105-113 (any hit) + the radiance add of pathintegrator.rs:35
+//   accumulate  src/main.rs:205-208 (in-order f32 sum over samples, then * 1/spp)
+//
+// One lane owns one path for the whole pass; path state is SoA in HBM at a fixed slot
+// (slot = k * P + pixel: lanes of a wave are neighbouring pixels of one sample index, so every
+// column access is a coalesced 256-byte row per wave).  Stages communicate through u32 slot queues;
+// the `break`s of the bounce loop (pathintegrator.rs:25-27, :48-50, :67-69) become "not appended to
+// the next queue", compacted with __ballot + mbcnt prefix + one atomicAdd per wave.
+#pragma once
+#include "lights.h"
+
+struct PathState {
+    float *ox, *oy, *oz, *dx, *dy, *dz;  // current ray (t_max is always +inf for path rays: Ray::new)
+    float *br, *bg, *bb;                 // beta
+    float *lr, *lg, *lb;                 // radiance
+    uint64_t* rng;
+    uint32_t* flags;  // bit 0: specular_bounce
+    float* ht;        // hit record
+    uint32_t *hinst, *hprim;
+    float *hb1, *hb2;
+    // next-event estimation hand-off to the shadow stage
+    float* so[2][3];
+    float* sd[2][3];
+    float* sc[2][3];
+    float* stmax[2];  // < 0: ray not cast
+    float* nb[3];     // beta at the time of the estimate
+    float* nscale;    // 1 / light_pdf
+    uint32_t* nmode;  // 0 area (sum of the two MIS terms), 1 delta, 2 env
+};
+#define PBRS_STATE_WORDS 47
+
+struct RenderConst {
+    pbrs_camera cam;
+    uint32_t x0, y0, w, h;
+    uint32_t strata_x, strata_y;
+    uint32_t max_depth;
+    uint32_t pass_first_sample;  // sample index of k = 0 in this pass
+    uint32_t n_pixels;           // P
+    uint32_t n_slots;            // P * K of this pass
+    uint64_t seed;
+};
+
+PD uint32_t lane_prefix(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// Stream compaction: every lane of the wave must call this; returns the output index for lanes with pred.
+PD uint32_t wave_append(bool pred, uint32_t* counter) {
+    uint64_t mask = __ballot(pred);
+    if (mask == 0) return 0;
+    uint32_t total = (uint32_t)__popcll(mask);
+    int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, total);
+    base = __shfl(base, leader, 64);
+    return base + lane_prefix(mask);
+}
+
+PD f3 ld_col(const float* a, const float* b, const float* c, uint32_t i) { return mk3(a[i], b[i], c[i]); }
+PD void st_col(float* a, float* b, float* c, uint32_t i, f3 v) {
+    a[i] = v.x;
+    b[i] = v.y;
+    c[i] = v.z;
+}
+
+// ---- raygen --------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= rc.n_slots) return;
+    uint32_t k = slot / rc.n_pixels, pix = slot - k * rc.n_pixels;
+    uint32_t col = rc.x0 + pix % rc.w, row = rc.y0 + pix / rc.w;
+    uint32_t i = rc.pass_first_sample + k;
+    uint64_t rng = pn_rng_init(rc.seed, row * rc.cam.width + col, i);
+    float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);
+    // src/main.rs:198-201 with msaa -> (strata_x, strata_y): i / msaa, i % msaa
+    float jx = ((float)(i / rc.strata_y) + r0) / (float)rc.strata_x;
+    float jy = ((float)(i % rc.strata_y) + r1) / (float)rc.strata_y;
+    // Camera::shoot_ray, camera.rs:65-77
+    float x = (float)col + pn_fract(jx);
+    float y = (float)row + pn_fract(jy);
+    f3 dir = ld3(rc.cam.c) + ld3(rc.cam.a) * x + ld3(rc.cam.b) * y;
+    st_col(st.ox, st.oy, st.oz, slot, ld3(rc.cam.center));
+    st_col(st.dx, st.dy, st.dz, slot, dir);
+    st_col(st.br, st.bg, st.bb, slot, gray(1.0f));
+    st_col(st.lr, st.lg, st.lb, slot, gray(0.0f));
+    st.rng[slot] = rng;
+    st.flags[slot] = 0u;
+}
+
+struct GlobalCounters {  // instrumented variant only
+    unsigned long long tlas_nodes, blas_nodes, instances, instance_hits, triangles, tri_shading, spheres, quads, cuboids, disks, rays, hits;
+};
+template <bool STATS>
+PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uint32_t rays, uint32_t hits) {
+    if (!STATS) return;
+    const WorkCounters& c = cnt.c;
+    uint32_t v[12] = {c.tlas_nodes, c.blas_nodes, c.instances, c.instance_hits, c.triangles, c.tri_shading,
+                      c.spheres,    c.quads,      c.cuboids,   c.disks,         rays,        hits};
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(g);
+    for (int k = 0; k < 12; ++k) {
+        uint32_t x = valid ? v[k] : 0u;
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63u) == 0 && x) atomicAdd(out + k, (unsigned long long)x);
+    }
+}
+
+// ---- extend ----------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t n_direct,
+                                               GlobalCounters* gc) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = queue ? *count : n_direct;
+    bool valid = i < n;
+    Cnt<STATS> cnt;
+    cnt.init();
+    uint32_t nhit = 0;
+    if (valid) {
+        uint32_t slot = queue ? queue[i] : i;
+        f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
+        LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
+        Hit h;
+        tlas_closest<STATS>(S, o, d, pn_inf(), stk, h, cnt);
+        nhit = h.inst != 0xffffffffu ? 1u : 0u;
+        st.ht[slot] = h.t;
+        st.hinst[slot] = h.inst;
+        st.hprim[slot] = h.prim;
+        st.hb1[slot] = h.b1;
+        st.hb2[slot] = h.b2;
+    }
+    flush_counters<STATS>(cnt, gc, valid, 1u, nhit);
+}
+
+PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:224-232, BETA = 2, nf = ng = 1
+    float f = 1.0f * f_pdf;
+    float g = 1.0f * g_pdf;
+    return pn_powi(f, 2) / (pn_powi(f, 2) + pn_powi(g, 2));
+}
+
+// ---- shade -----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* queue,
+                                              const uint32_t* count, uint32_t n_direct, uint32_t* queue_out, uint32_t* count_out,
+                                              uint32_t* shadow_queue, uint32_t* shadow_count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = queue ? *count : n_direct;
+    bool valid = i < n;
+    bool alive = false, want_shadow = false;
+    uint32_t slot = 0;
+    if (valid) {
+        slot = queue ? queue[i] : i;
+        f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
+        f3 beta = ld_col(st.br, st.bg, st.bb, slot);
+        f3 L = ld_col(st.lr, st.lg, st.lb, slot);
+        uint32_t flags = st.flags[slot];
+        Hit h;
+        h.t = st.ht[slot];
+        h.inst = st.hinst[slot];
+        h.prim = st.hprim[slot];
+        bool has_hit = h.inst != 0xffffffffu;
+        bool specular_bounce = (flags & 1u) != 0;
+        const pbrs_material* mat = nullptr;
+        if (has_hit) mat = S.mats + S.inst[h.inst].material;
+        if (bounce == 0 || specular_bounce) {  // pathintegrator.rs:19-22
+            f3 e = has_hit ? ld3(mat->emission) : ld3(S.env);
+            L = L + cmul(beta, e);
+        }
+        if (has_hit) {
+            uint64_t rng = st.rng[slot];
+            Isect is = reconstruct_isect(S, h, o, d);
+            Bsdf bs = bsdf_new_frame(is, S.bxdfs + mat->first_bxdf, mat->n_bxdfs);
+
+            // uniform_sample_one_light, directlighting.rs:58-99
+            uint32_t num_lights = S.n_delta + S.n_area + S.has_env;
+            if (num_lights > 0) {
+                float light_pdf = 1.0f / (float)num_lights;
+                float uidx = pn_rng_f32(&rng);
+                uint32_t chosen = (uint32_t)(uidx * (float)num_lights);
+                if (chosen > num_lights - 1) chosen = num_lights - 1;
+                float lu = pn_rng_f32(&rng), lv = pn_rng_f32(&rng);
+                float su = pn_rng_f32(&rng), sv = pn_rng_f32(&rng);
+                float scale = 1.0f / light_pdf;
+                f3 c1 = gray(0.0f), c2 = gray(0.0f);
+                ShadowRay v1, v2;
+                v1.t_max = -1.0f;
+                v2.t_max = -1.0f;
+                v1.o = v1.d = v2.o = v2.d = gray(0.0f);
+                uint32_t mode;
+                if (chosen < S.n_delta) {  // estimate_direct_delta_light :101-153
+                    mode = 1;
+                    f3 li, wi;
+                    ShadowRay vis;
+                    delta_sample_incident(S.dlights[chosen], is, li, wi, vis);
+                    f3 bv = bsdf_eval(bs, is.wo, wi) * pn_abs(dot(is.normal, wi));
+                    if (!(is_black(li) || is_black(bv))) {
+                        c1 = cmul(bv, li) * 1.0f * pn_weak_recip(1.0f);
+                        v1 = vis;
+                    }
+                } else if (chosen >= S.n_delta && chosen < S.n_area) {  // Q6 guard; estimate_direct_area_light :155-222
+                    mode = 0;
+                    const pbrs_area_light& Lt = S.alights[chosen - S.n_delta];
+                    f3 li, wi;
+                    float lpdf;
+                    ShadowRay vis;
+                    area_sample_incident(Lt, is, lu, lv, li, wi, lpdf, vis);
+                    if (lpdf > 0.0f && !is_black(li)) {
+                        f3 bv = bsdf_eval(bs, is.wo, wi) * pn_abs(dot(is.normal, wi));
+                        float spdf = bsdf_pdf(bs, is.wo, wi);
+                        if (!is_black(bv) && spdf > 0.0f) {
+                            float weight = power_heuristic2(lpdf, spdf);
+                            c1 = cmul(bv, li) * weight * pn_weak_recip(lpdf);
+                            v1 = vis;
+                        }
+                    }
+                    f3 f2, wi2;
+                    ProbD pr2;
+                    bsdf_sample(bs, is.wo, su, sv, f2, wi2, pr2);
+                    f2 = f2 * pn_abs(dot(is.normal, wi2));
+                    if (!(is_black(f2) || !(pr2.v > 0.0f))) {
+                        f3 le;
+                        float lpdf2;
+                        ShadowRay vis2;
+                        if (area_radiance_to(Lt, is, wi2, le, lpdf2, vis2)) {
+                            if (!(is_black(le) || lpdf2 <= 0.0f)) {
+                                float weight = pr2.is_mass ? 1.0f : power_heuristic2(pr2.v, lpdf2);
+                                c2 = (weight * cmul(f2, le)) * pn_weak_recip(pr2.v);
+                                v2 = vis2;
+                            }
+                        }
+                    }
+                } else {  // :80-96 environment
+                    mode = 2;
+                    f3 f2, wi2;
+                    ProbD pr2;
+                    bsdf_sample(bs, is.wo, su, sv, f2, wi2, pr2);
+                    spawn_ray(is, wi2, v1.o, v1.d);
+                    v1.t_max = pn_inf();
+                    float ac = pn_abs(dot(wi2, is.normal));
+                    float wr = pn_weak_recip(pr2.v);
+                    c1 = cmul(ld3(S.env), f2) * ac * wr;
+                    c2 = cmul(gray(0.0f), f2) * ac * wr;  // Color::black() * f * ..., the occluded arm
+                }
+                if (v1.t_max >= 0.0f || v2.t_max >= 0.0f) {
+                    want_shadow = true;
+                    for (int r = 0; r < 3; ++r) {
+                        st.so[0][r][slot] = comp(v1.o, r);
+                        st.sd[0][r][slot] = comp(v1.d, r);
+                        st.sc[0][r][slot] = comp(c1, r);
+                        st.so[1][r][slot] = comp(v2.o, r);
+                        st.sd[1][r][slot] = comp(v2.d, r);
+                        st.sc[1][r][slot] = comp(c2, r);
+                        st.nb[r][slot] = comp(beta, r);
+                    }
+                    st.stmax[0][slot] = v1.t_max;
+                    st.stmax[1][slot] = v2.t_max;
+                    st.nscale[slot] = scale;
+                    st.nmode[slot] = mode;
+                } else {
+                    // nothing to test: the estimate is black; pathintegrator.rs:35 still adds beta * (black * n)
+                    L = L + cmul(beta, gray(0.0f) * scale);
+                }
+            }
+
+            // pathintegrator.rs:46-71
+            float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);
+            f3 f, wi;
+            ProbD pr;
+            bsdf_sample(bs, -d, r0, r1, f, wi, pr);
+            if (!(is_black(f) || pr.v == 0.0f)) {
+                specular_bounce = pr.is_mass;
+                beta = cmul(beta, f) * dot(wi, is.normal) * pn_recip(pr.v);  // Q9: no abs
+                f3 no, nd;
+                spawn_ray(is, wi, no, nd);
+                bool cont = true;
+                if (bounce > 3) {
+                    float q = pn_max(1.0f - luminance(beta), 0.05f);
+                    if (pn_rng_f32(&rng) < q)
+                        cont = false;
+                    else
+                        beta = beta * pn_recip(1.0f - q);
+                }
+                if (cont && bounce + 1 < rc.max_depth) {
+                    alive = true;
+                    st_col(st.ox, st.oy, st.oz, slot, no);
+                    st_col(st.dx, st.dy, st.dz, slot, nd);
+                    st_col(st.br, st.bg, st.bb, slot, beta);
+                    st.rng[slot] = rng;
+                    st.flags[slot] = specular_bounce ? 1u : 0u;
+                }
+            }
+        }
+        st_col(st.lr, st.lg, st.lb, slot, L);
+    }
+    uint32_t p = wave_append(alive, count_out);
+    if (alive) queue_out[p] = slot;
+    uint32_t ps = wave_append(want_shadow, shadow_count);
+    if (want_shadow) shadow_queue[ps] = slot;
+}
+
+// ---- shadow ----------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, GlobalCounters* gc) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = i < *count;
+    Cnt<STATS> cnt;
+    cnt.init();
+    uint32_t nrays = 0;
+    if (valid) {
+        uint32_t slot = queue[i];
+        LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
+        bool cast[2], occ[2];
+        for (int r = 0; r < 2; ++r) {
+            float tm = st.stmax[r][slot];
+            cast[r] = tm >= 0.0f;
+            occ[r] = false;
+            if (cast[r]) {
+                f3 o = mk3(st.so[r][0][slot], st.so[r][1][slot], st.so[r][2][slot]);
+                f3 d = mk3(st.sd[r][0][slot], st.sd[r][1][slot], st.sd[r][2][slot]);
+                occ[r] = tlas_any<STATS>(S, o, d, tm, stk, cnt);
+                nrays++;
+            }
+        }
+        f3 c1 = mk3(st.sc[0][0][slot], st.sc[0][1][slot], st.sc[0][2][slot]);
+        f3 c2 = mk3(st.sc[1][0][slot], st.sc[1][1][slot], st.sc[1][2][slot]);
+        uint32_t mode = st.nmode[slot];
+        f3 one;
+        if (mode == 0) {  // directlighting.rs:193, :219: radiance_d += term, in this order
+            one = gray(0.0f);
+            if (cast[0] && !occ[0]) one = one + c1;
+            if (cast[1] && !occ[1]) one = one + c2;
+        } else if (mode == 1) {
+            one = occ[0] ? gray(0.0f) : c1;
+        } else {
+            one = occ[0] ? c2 : c1;
+        }
+        f3 nb = mk3(st.nb[0][slot], st.nb[1][slot], st.nb[2][slot]);
+        f3 L = ld_col(st.lr, st.lg, st.lb, slot);
+        L = L + cmul(nb, one * st.nscale[slot]);  // directlighting.rs:98, pathintegrator.rs:35
+        st_col(st.lr, st.lg, st.lb, slot, L);
+    }
+    flush_counters<STATS>(cnt, gc, valid, nrays, 0u);
+}
+
+// ---- accumulate / finalize -----------------------------------------------------------------------------------------
+// color_sum = color_sum + integrator(...) for strictly increasing sample index (src/main.rs:205)
+__global__ void __launch_bounds__(256) k_accumulate(PathState st, float* sum, uint32_t n_pixels, uint32_t k_count) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    f3 s = mk3(sum[p], sum[n_pixels + p], sum[2 * n_pixels + p]);
+    for (uint32_t k = 0; k < k_count; ++k) {
+        uint32_t slot = k * n_pixels + p;
+        s = s + ld_col(st.lr, st.lg, st.lb, slot);
+    }
+    sum[p] = s.x;
+    sum[n_pixels + p] = s.y;
+    sum[2 * n_pixels + p] = s.z;
+}
+// color_sum.scale_down_by(msaa*msaa) (src/main.rs:208, color.rs:90-95): * (1.0 / n as f32); planar -> row-major RGB
+__global__ void __launch_bounds__(256) k_finalize(const float* sum, float* rgb, uint32_t n_pixels, float inv_spp) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    rgb[3 * p] = sum[p] * inv_spp;
+    rgb[3 * p + 1] = sum[n_pixels + p] * inv_spp;
+    rgb[3 * p + 2] = sum[2 * n_pixels + p] * inv_spp;
+}
+
+// ---- parity-harness kernels --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, const float* origins, const float* dirs, const float* tmax,
+                                                       pbrs_hit_record* hits, uint8_t* occluded) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 o = ld3(origins + 3 * i), d = ld3(dirs + 3 * i);
+    LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
+    Cnt<false> cnt;
+    if (hits) {
+        Hit h;
+        tlas_closest<false>(S, o, d, tmax[i], stk, h, cnt);
+        pbrs_hit_record r;
+        r.t = h.t;
+        r.inst = h.inst;
+        r.prim = 0;
+        if (h.inst != 0xffffffffu && S.inst[h.inst].shape_kind == PBRS_SHAPE_MESH) r.prim = S.tv[h.prim].orig;
+        r.b1 = h.b1;
+        r.b2 = h.b2;
+        hits[i] = r;
+    }
+    if (occluded) occluded[i] = tlas_any<false>(S, o, d, tmax[i], stk, cnt) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_numeric_eval(uint32_t fn, uint32_t n, const float* x, const float* y, float* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = x[i], b = y ? y[i] : 0.0f, r = 0.0f;
+    switch (fn) {
+        case 0: r = pn_sin(a); break;
+        case 1: r = pn_cos(a); break;
+        case 2: r = pn_tan(a); break;
+        case 3: r = pn_atan(a); break;
+        case 4: r = pn_atan2(a, b); break;
+        case 5: r = pn_acos(a); break;
+        case 6: r = pn_exp(a); break;
+        case 7: r = pn_ln(a); break;
+        case 8: r = pn_hypot(a, b); break;
+        case 9: r = a / b; break;
+        case 10: r = pn_sqrt(a); break;
+        case 11: r = pn_asin(a); break;
+        case 12: r = pn_powi(a, (int)b); break;
+        case 13: r = pn_fract(a); break;
+        case 14: r = pn_floor(a); break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+__global__ void __launch_bounds__(256) k_export_rays(PathState st, uint32_t n, float* origins, float* dirs) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    origins[3 * i] = st.ox[i]; origins[3 * i + 1] = st.oy[i]; origins[3 * i + 2] = st.oz[i];
+    dirs[3 * i] = st.dx[i]; dirs[3 * i + 1] = st.dy[i]; dirs[3 * i + 2] = st.dz[i];
+}
+__global__ void __launch_bounds__(256) k_export_radiance(PathState st, uint32_t n, float* rgb) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rgb[3 * i] = st.lr[i]; rgb[3 * i + 1] = st.lg[i]; rgb[3 * i + 2] = st.lb[i];
+}

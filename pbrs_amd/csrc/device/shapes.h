@@ -1,0 +1,626 @@
+// device/shapes.h — primitive intersection and two-level BVH traversal for the `extend` (closest
+// hit) and `shadow` (any hit) stages.
+//
+// Restates, for one lane = one ray: shape/src/simple.rs (Sphere :207-288, Disk :306-332,
+// ParallelQuad :120-163, Cuboid :343-415, intersect_triangle :435-495), shape/src/blas.rs
+// (TriangleMesh::intersect_triangle :161-211, intersect_bvh :422-476, intersect_bvh_pred :478-495),
+// tlas/src/instance.rs:50-72 and tlas/src/bvh.rs:77-113.  The reference recurses over Box-linked
+// nodes; here the trees are flat pre-order arrays in HBM and the pending nodes live in a per-lane
+// LDS stack laid out lane-major (stack[level][lane]: conflict-free for a wave).
+#pragma once
+#include "../../../include/pbrs_gpu.h"
+#include "../../../include/pbrs_scene_spec.h"
+#include "dmath.h"
+
+struct DevScene {
+    const pbrs_node* tlas;
+    const pbrs_instance* inst;
+    const pbrs_shape* shapes;
+    const pbrs_mesh* meshes;
+    const pbrs_node* blas;
+    const pbrs_tri_verts* tv;
+    const pbrs_tri_shade* ts;
+    const pbrs_material* mats;
+    const pbrs_bxdf* bxdfs;
+    const pbrs_area_light* alights;
+    const pbrs_delta_light* dlights;
+    uint32_t n_area, n_delta;
+    float env[3];
+    uint32_t has_env;
+};
+
+// Per-lane work counters (instrumented kernel variant only; SURVEY.md §8(d) units).
+struct WorkCounters {
+    uint32_t tlas_nodes, blas_nodes, instances, instance_hits, triangles, tri_shading, spheres, quads, cuboids, disks;
+};
+template <bool STATS>
+struct Cnt {
+    WorkCounters c;
+    PD void init() {
+        if (STATS) c = WorkCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    }
+};
+#define CNT(field)             \
+    do {                       \
+        if (STATS) cnt.c.field++; \
+    } while (0)
+
+// Interaction::with_dpdu (geometry/src/interaction.rs:45-61): returns tbn.cols[0].
+PD f3 with_dpdu(f3 normal, f3 dpdu) {
+    f3 n = hat(normal);
+    f3 bitangent = hat(cross(n, dpdu));
+    return cross(bitangent, n);
+}
+
+// What shade needs of geometry/src/interaction.rs:12-20 (uv is only read by non-Solid textures, which
+// are outside this tier: not carried).
+struct Isect {
+    f3 pos, normal, wo, tangent;
+};
+
+// ---- Sphere (shape/src/simple.rs:207-288) ----------------------------------------------------------------
+PD bool sphere_roots(f3 center, float radius, f3 o, f3 d, float& t0, float& t1) {
+    f3 f = o - center;
+    float a = norm2(d);
+    float b_prime = -dot(f, d);
+    float delta = radius * radius - norm2(f + b_prime / a * d);
+    if (delta < 0.0f) return false;
+    float c = norm2(f) - radius * radius;
+    float q = b_prime + pn_signum(b_prime) * pn_sqrt(delta * a);
+    t0 = c / q;
+    t1 = q / a;
+    return true;
+}
+PD bool sphere_hit_t(f3 center, float radius, f3 o, f3 d, float t_max, float& t) {
+    float t0, t1;
+    if (!sphere_roots(center, radius, o, d, t0, t1)) return false;
+    float t_low = t0 < t1 ? t0 : t1;
+    float t_high = t0 < t1 ? t1 : t0;
+    if (truncated_t(t_low, t_max)) {
+        t = t_low;
+        return true;
+    }
+    if (truncated_t(t_high, t_max)) {
+        t = t_high;
+        return true;
+    }
+    return false;
+}
+PD bool sphere_occludes(f3 center, float radius, f3 o, f3 d, float t_max) {  // :268-288 (Q13)
+    float t0, t1;
+    if (!sphere_roots(center, radius, o, d, t0, t1)) return false;
+    return truncated_t(t0, t_max) && truncated_t(t1, t_max);
+}
+PD Isect sphere_isect(f3 center, float radius, f3 o, f3 d, float t) {  // :241-266
+    f3 pos = o + t * d;
+    f3 normal = hat(pos - center);
+    pos = center + normal * radius * 1.00001f;
+    f3 dpdu;
+    if (!try_hat(mk3(-normal.y, normal.x, 0.0f), dpdu)) dpdu = mk3(1.0f, 0.0f, 0.0f);
+    Isect i;
+    i.pos = pos;
+    i.normal = normal;  // always outward: D4, interior hits keep n·wo < 0
+    i.wo = -d;
+    i.tangent = with_dpdu(normal, dpdu);
+    return i;
+}
+
+// ---- Disk (:306-332) ------------------------------------------------------------------------------------
+PD bool disk_hit_t(f3 center, f3 normal, f3 radial, f3 o, f3 d, float t_max, float& t) {
+    float tt = dot(center - o, normal) / dot(d, normal);
+    if (!truncated_t(tt, t_max)) return false;
+    f3 p = o + tt * d;
+    if (!(norm2(p - center) <= norm2(radial))) return false;
+    t = tt;
+    return true;
+}
+PD bool disk_occludes(f3 center, f3 normal, f3 radial, f3 o, f3 d) {  // Q14: no t range
+    float tt = dot(center - o, normal) / dot(d, normal);
+    f3 p = o + tt * d;
+    return norm2(p - center) <= norm2(radial);
+}
+PD Isect disk_isect(f3 center, f3 dn, f3 o, f3 d, float t) {
+    f3 p = o + t * d;
+    f3 cp = p - center;
+    cp = cp - dot(cp, dn) * dn;
+    f3 normal = dn * pn_signum(dot(dn, -d));
+    f3 tan = hat(cross(normal, cp));
+    Isect i;
+    i.pos = center + cp;
+    i.normal = normal;
+    i.wo = -d;
+    i.tangent = with_dpdu(normal, tan);
+    return i;
+}
+
+// ---- ParallelQuad (:120-163; defects D1/D2 kept) ---------------------------------------------------------
+PD bool quad_hit(f3 origin, f3 su, f3 sv, f3 o, f3 d, float t_max, float& t, float& u, float& v, f3& nrm) {
+    f3 normal = facing(cross(su, sv), d);
+    float tt = dot(origin - o, normal) / dot(d, normal);
+    if (!truncated_t(tt, t_max)) return false;
+    f3 coarse = o + tt * d;
+    f3 dd = coarse - origin;
+    float vv = norm(cross(su, dd)) / norm(cross(su, sv));
+    float uu = norm(cross(sv, dd)) / norm(cross(sv, su));
+    if (!((0.0f <= vv && vv <= 1.0f) && (0.0f <= uu && uu <= 1.0f))) return false;
+    t = tt;
+    u = uu;
+    v = vv;
+    nrm = normal;
+    return true;
+}
+PD bool quad_occludes(f3 origin, f3 su, f3 sv, f3 o, f3 d, float t_max) {  // D2: reciprocal t
+    f3 normal = cross(su, sv);
+    float tt = dot(d, normal) / dot(origin - o, normal);
+    if (!truncated_t(tt, t_max)) return false;
+    f3 coarse = o + tt * d;
+    f3 dd = coarse - origin;
+    float vv = norm(cross(su, dd)) / norm(cross(su, sv));
+    float uu = norm(cross(sv, dd)) / norm(cross(sv, su));
+    return (0.0f <= vv && vv <= 1.0f) && (0.0f <= uu && uu <= 1.0f);
+}
+PD Isect quad_isect(f3 origin, f3 su, f3 sv, f3 o, f3 d) {
+    float t, u, v;
+    f3 normal;
+    quad_hit(origin, su, sv, o, d, pn_inf(), t, u, v, normal);
+    Isect i;
+    i.pos = origin + u * su + sv * v;
+    i.normal = hat(normal);
+    i.wo = -d;
+    i.tangent = with_dpdu(i.normal, su);
+    return i;
+}
+
+// ---- Cuboid (:343-415) ------------------------------------------------------------------------------------
+PD bool cuboid_hit(f3 bmin, f3 bmax, f3 o, f3 d, float t_max, float& t, int& axis_out, float& bound_out) {
+    float min_t = 0.0f, min_bound = pn_inf();
+    int min_axis = 0;
+    float max_t = t_max, max_bound = -pn_inf();
+    int max_axis = 0;
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis) {
+        float inv_dir = 1.0f / comp(d, axis);
+        float t0 = (comp(bmin, axis) - comp(o, axis)) * inv_dir;
+        float t1 = (comp(bmax, axis) - comp(o, axis)) * inv_dir;
+        float b0 = comp(bmin, axis), b1 = comp(bmax, axis);
+        if (t0 > t1) {
+            float tmp = t0; t0 = t1; t1 = tmp;
+            tmp = b0; b0 = b1; b1 = tmp;
+        }
+        if (t0 > min_t) {
+            min_t = t0; min_bound = b0; min_axis = axis;
+        }
+        if (t1 < max_t) {
+            max_t = t1; max_bound = b1; max_axis = axis;
+        }
+        if (max_t < min_t) return false;
+    }
+    float lo = min_t < max_t ? min_t : max_t;
+    float hi = min_t < max_t ? max_t : min_t;
+    bool inside = (0.0f >= lo && 0.0f <= hi);
+    float ht = inside ? max_t : min_t;
+    float hb = inside ? max_bound : min_bound;
+    int ha = inside ? max_axis : min_axis;
+    if (pn_isinf(hb)) return false;
+    t = ht;
+    axis_out = ha;
+    bound_out = hb;
+    return true;
+}
+PD Isect cuboid_isect(f3 bmin, f3 bmax, f3 o, f3 d) {
+    float t, bound;
+    int axis;
+    cuboid_hit(bmin, bmax, o, d, pn_inf(), t, axis, bound);
+    f3 pos = o + t * d;
+    setc(pos, axis, bound);
+    f3 normal = mk3(0.0f, 0.0f, 0.0f);
+    setc(normal, axis, pn_signum(comp(d, axis)) * -1.0f);
+    f3 tan = mk3(0.0f, 0.0f, 0.0f);
+    setc(tan, (axis + 1) % 3, 1.0f);
+    Isect i;
+    i.pos = pos;
+    i.normal = normal;
+    i.wo = -d;
+    i.tangent = with_dpdu(normal, tan);
+    return i;
+}
+
+// ---- triangles (simple.rs:435-495) -------------------------------------------------------------------------
+struct TriHit {
+    float t, b0, b1, b2;
+    f3 normal;
+};
+PD bool tri_hit(f3 p0, f3 p1, f3 p2, f3 o, f3 d, float t_max, TriHit& h) {
+    f3 normal;
+    if (!try_hat(cross(p0 - p1, p2 - p1), normal)) return false;
+    normal = facing(normal, d);
+    float t = dot(normal, p0 - o) / dot(normal, d);
+    if (!truncated_t(t, t_max)) return false;
+    f3 p = o + t * d;
+    float b2 = dot(cross(p - p0, p - p1), normal);
+    float b0 = dot(cross(p - p1, p - p2), normal);
+    float b1 = dot(cross(p - p2, p - p0), normal);
+    if (pn_isnan(b0) || pn_isnan(b1) || pn_isnan(b2)) return false;
+    bool s0 = b0 > 0.0f, s1 = b1 > 0.0f, s2 = b2 > 0.0f;
+    if (!((s0 && s1 && s2) || (!s0 && !s1 && !s2))) return false;
+    float total_area = b0 + b1 + b2;
+    b0 = b0 / total_area;
+    b1 = b1 / total_area;
+    b2 = b2 / total_area;
+    f3 hit_pos = bary_lerp(p0, p1, p2, b0, b1);
+    if (has_nan3(hit_pos)) return false;
+    h.t = t;
+    h.b0 = b0;
+    h.b1 = b1;
+    h.b2 = b2;
+    h.normal = normal;
+    return true;
+}
+PD bool tri_pred(f3 p0, f3 p1, f3 p2, f3 o, f3 d, float t_max) {
+    f3 normal;
+    if (!try_hat(cross(p0 - p1, p2 - p1), normal)) return false;
+    float t = dot(normal, p0 - o) / dot(normal, d);
+    if (!truncated_t(t, t_max)) return false;
+    f3 p = o + t * d;
+    float b0 = dot(cross(p - p0, p - p1), normal);
+    float b1 = dot(cross(p - p1, p - p2), normal);
+    float b2 = dot(cross(p - p2, p - p0), normal);
+    bool s0 = b0 > 0.0f, s1 = b1 > 0.0f, s2 = b2 > 0.0f;
+    return (s0 && s1 && s2) || (!s0 && !s1 && !s2);
+}
+// TriangleMesh::intersect_triangle past the geometric test (blas.rs:166-206): shading normal, tangent,
+// and the Q22 rejection `abs(dpdu·n) >= 1e-3`.
+PD bool mesh_tri_shading(const pbrs_tri_verts& tv, const pbrs_tri_shade& ts, f3 d, const TriHit& h, f3& normal_out, f3& dpdu_out) {
+    f3 p0 = ld3(tv.p0), p1 = ld3(tv.p1), p2 = ld3(tv.p2);
+    float hb1 = h.b1, hb2 = h.b2;  // hit.uv
+    float b0 = 1.0f - hb1 - hb2, b1 = hb1;
+    f3 n;
+    if (!try_hat(bary_lerp(ld3(ts.n0), ld3(ts.n1), ld3(ts.n2), b0, b1), n)) n = h.normal;
+    n = facing(n, d);
+    float u0 = ts.uv0[0], v0 = ts.uv0[1];
+    float u1 = ts.uv1[0] - u0, v1 = ts.uv1[1] - v0;
+    float u2 = ts.uv2[0] - u0, v2 = ts.uv2[1] - v0;
+    f3 dpdu = ((p2 - p0) * v2 - (p1 - p0) * v1) / (u1 * v2 - u2 * v1);
+    if (!pn_isfinite(norm2(dpdu))) dpdu = p1 - p0;
+    dpdu = hat(dpdu - projected_onto(dpdu, n));
+    if (pn_abs(dot(dpdu, n)) >= 1e-3f) return false;
+    normal_out = n;
+    dpdu_out = dpdu;
+    return true;
+}
+
+struct Hit {
+    float t;
+    uint32_t inst, prim;
+    float b1, b2;
+};
+
+PD f3 nmin(const pbrs_node& n) { return mk3(n.min[0], n.min[1], n.min[2]); }
+PD f3 nmax(const pbrs_node& n) { return mk3(n.max[0], n.max[1], n.max[2]); }
+
+// Loads one 32-byte node as two 16-byte vectors (coalescing unit of the LDS/HBM path on gfx950).
+PD pbrs_node load_node(const pbrs_node* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    float4 a = q[0], b = q[1];
+    pbrs_node n;
+    n.min[0] = a.x; n.min[1] = a.y; n.min[2] = a.z; n.a = __float_as_uint(a.w);
+    n.max[0] = b.x; n.max[1] = b.y; n.max[2] = b.z; n.b = __float_as_uint(b.w);
+    return n;
+}
+PD pbrs_tri_verts load_tri(const pbrs_tri_verts* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    float4 a = q[0], b = q[1], c = q[2];
+    pbrs_tri_verts t;
+    t.p0[0] = a.x; t.p0[1] = a.y; t.p0[2] = a.z; t.orig = __float_as_uint(a.w);
+    t.p1[0] = b.x; t.p1[1] = b.y; t.p1[2] = b.z; t.pad1 = 0.0f;
+    t.p2[0] = c.x; t.p2[1] = c.y; t.p2[2] = c.z; t.pad2 = 0.0f;
+    return t;
+}
+
+// A per-lane stack in LDS: entry `level` of lane `lane` at stk[level * stride + lane].
+struct LaneStack {
+    uint32_t* base;  // &lds[lane]
+    uint32_t stride; // threads per block
+    PD void put(int level, uint32_t v) { base[level * stride] = v; }
+    PD uint32_t get(int level) const { return base[level * stride]; }
+};
+
+// intersect_bvh (shape/src/blas.rs:422-476) over the flat BLAS, entries pushed above `sp`.
+template <bool STATS>
+PD bool blas_closest(const DevScene& S, const pbrs_mesh& mesh, f3 o, f3 d, float t_max_in, LaneStack stk, int sp, float& out_t, uint32_t& out_prim,
+                     float& out_b1, float& out_b2, Cnt<STATS>& cnt) {
+    const int base = sp;
+    stk.put(sp++, mesh.root);
+    float ray_t_max = t_max_in;  // `let mut ray = r.clone()`
+    float best_t = pn_inf();     // outer_hit.ray_t
+    uint32_t best_prim = 0;
+    float best_b1 = 0.0f, best_b2 = 0.0f;
+    while (sp > base) {
+        uint32_t ni = stk.get(--sp);
+        pbrs_node node = load_node(S.blas + ni);
+        CNT(blas_nodes);
+        if (!slab_test(nmin(node), nmax(node), o, d, ray_t_max)) continue;
+        if (node.b & PBRS_LEAF_FLAG) {
+            uint32_t count = node.b & ~PBRS_LEAF_FLAG;
+            for (uint32_t k = 0; k < count; ++k) {
+                uint32_t ti = node.a + k;
+                pbrs_tri_verts tv = load_tri(S.tv + ti);
+                CNT(triangles);
+                TriHit h;
+                if (!tri_hit(ld3(tv.p0), ld3(tv.p1), ld3(tv.p2), o, d, ray_t_max, h)) continue;
+                CNT(tri_shading);
+                // The reference evaluates the shading frame for every geometric hit (blas.rs:166-206);
+                // only hits that would replace outer_hit can change the result, so only those pay for it.
+                if (!(h.t < best_t)) continue;
+                f3 n, dpdu;
+                if (!mesh_tri_shading(tv, S.ts[ti], d, h, n, dpdu)) continue;
+                best_t = h.t;
+                best_prim = ti;
+                best_b1 = h.b1;
+                best_b2 = h.b2;
+            }
+        } else {
+            uint32_t axis = node.b & 3u;
+            uint32_t left = ni + 1, right = node.a;
+            if (comp(d, (int)axis) > 0.0f) {
+                stk.put(sp++, right);
+                stk.put(sp++, left);
+            } else {
+                stk.put(sp++, left);
+                stk.put(sp++, right);
+            }
+        }
+        ray_t_max = best_t;  // blas.rs:468 (not reached on a bbox miss)
+    }
+    if (best_t < pn_inf()) {
+        out_t = best_t;
+        out_prim = best_prim;
+        out_b1 = best_b1;
+        out_b2 = best_b2;
+        return true;
+    }
+    return false;
+}
+
+// intersect_bvh_pred (blas.rs:478-495): a pure OR over leaves reached through intersecting boxes, so
+// visiting order is free; depth-first with the same LDS stack.
+template <bool STATS>
+PD bool blas_any(const DevScene& S, const pbrs_mesh& mesh, f3 o, f3 d, float t_max, LaneStack stk, int sp, Cnt<STATS>& cnt) {
+    const int base = sp;
+    stk.put(sp++, mesh.root);
+    while (sp > base) {
+        uint32_t ni = stk.get(--sp);
+        pbrs_node node = load_node(S.blas + ni);
+        CNT(blas_nodes);
+        if (!slab_test(nmin(node), nmax(node), o, d, t_max)) continue;
+        if (node.b & PBRS_LEAF_FLAG) {
+            uint32_t count = node.b & ~PBRS_LEAF_FLAG;
+            for (uint32_t k = 0; k < count; ++k) {
+                pbrs_tri_verts tv = load_tri(S.tv + node.a + k);
+                CNT(triangles);
+                if (tri_pred(ld3(tv.p0), ld3(tv.p1), ld3(tv.p2), o, d, t_max)) return true;
+            }
+        } else {
+            stk.put(sp++, node.a);
+            stk.put(sp++, ni + 1);
+        }
+    }
+    return false;
+}
+
+// BvhNode::intersect (tlas/src/bvh.rs:77-103) + Instance::intersect (tlas/src/instance.rs:50-67, ray
+// transform and `t` only).  The recursion visits left then right with ray.t_max lowered to the left
+// result; iteratively: pop, test the box against the current t_max, push right then left.
+// Candidate replaces the best when !(best.t < cand.t), the rule of bvh.rs:94-98.
+// Known deviation: the reference can RAISE ray.t_max after a mesh instance
+// returns a hit beyond it (blas.rs:468 drops the incoming extent); here t_max is always the best t so
+// far.  The two differ only if two instances hit at bit-identical t (oracle counter `tlas_ties`).
+template <bool STATS>
+PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
+    best.t = pn_inf();
+    best.inst = 0xffffffffu;
+    best.prim = 0;
+    best.b1 = best.b2 = 0.0f;
+    bool have = false;
+    int sp = 0;
+    stk.put(sp++, 0u);
+    while (sp > 0) {
+        uint32_t ni = stk.get(--sp);
+        pbrs_node node = load_node(S.tlas + ni);
+        CNT(tlas_nodes);
+        if (!slab_test(nmin(node), nmax(node), o, d, t_max)) continue;
+        if (!(node.b & PBRS_LEAF_FLAG)) {
+            stk.put(sp++, node.a);
+            stk.put(sp++, ni + 1);
+            continue;
+        }
+        const pbrs_instance& in = S.inst[node.a];
+        CNT(instances);
+        f3 oo = xf_apply(in.inv, o, 1.0f);
+        f3 od = xf_apply(in.inv, d, 0.0f);
+        float t = 0.0f, b1 = 0.0f, b2 = 0.0f;
+        uint32_t prim = 0;
+        bool hit = false;
+        switch (in.shape_kind) {
+            case PBRS_SHAPE_SPHERE: {
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(spheres);
+                hit = sphere_hit_t(ld3(p), p[3], oo, od, t_max, t);
+                break;
+            }
+            case PBRS_SHAPE_QUAD: {
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(quads);
+                float u, v;
+                f3 n;
+                hit = quad_hit(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, t, u, v, n);
+                break;
+            }
+            case PBRS_SHAPE_CUBOID: {
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(cuboids);
+                int axis;
+                float bound;
+                hit = cuboid_hit(ld3(p), ld3(p + 3), oo, od, t_max, t, axis, bound);
+                break;
+            }
+            case PBRS_SHAPE_DISK: {
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(disks);
+                hit = disk_hit_t(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, t);
+                break;
+            }
+            case PBRS_SHAPE_TRIANGLE: {
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(triangles);
+                TriHit h;
+                hit = tri_hit(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, h);
+                if (hit) {
+                    t = h.t;
+                    b1 = h.b1;
+                    b2 = h.b2;
+                }
+                break;
+            }
+            default: {
+                pbrs_mesh mesh = S.meshes[in.shape_index];
+                hit = blas_closest<STATS>(S, mesh, oo, od, t_max, stk, sp, t, prim, b1, b2, cnt);
+                break;
+            }
+        }
+        if (!hit) continue;
+        CNT(instance_hits);
+        if (!have || !(best.t < t)) {
+            have = true;
+            best.t = t;
+            best.inst = node.a;
+            best.prim = prim;
+            best.b1 = b1;
+            best.b2 = b2;
+            t_max = t;  // ray.set_extent (bvh.rs:85-87); never raised — see the deviation note above
+        }
+    }
+}
+
+// BvhNode::occludes (bvh.rs:105-113) + Instance::occludes (instance.rs:68-72).
+template <bool STATS>
+PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
+    int sp = 0;
+    stk.put(sp++, 0u);
+    while (sp > 0) {
+        uint32_t ni = stk.get(--sp);
+        pbrs_node node = load_node(S.tlas + ni);
+        CNT(tlas_nodes);
+        if (!slab_test(nmin(node), nmax(node), o, d, t_max)) continue;
+        if (!(node.b & PBRS_LEAF_FLAG)) {
+            stk.put(sp++, node.a);
+            stk.put(sp++, ni + 1);
+            continue;
+        }
+        const pbrs_instance& in = S.inst[node.a];
+        CNT(instances);
+        f3 oo = xf_apply(in.inv, o, 1.0f);
+        f3 od = xf_apply(in.inv, d, 0.0f);
+        bool occ = false;
+        switch (in.shape_kind) {
+            case PBRS_SHAPE_SPHERE: {
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(spheres);
+                occ = sphere_occludes(ld3(p), p[3], oo, od, t_max);
+                break;
+            }
+            case PBRS_SHAPE_QUAD: {
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(quads);
+                occ = quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
+                break;
+            }
+            case PBRS_SHAPE_CUBOID: {  // Q14: the bbox slab test
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(cuboids);
+                occ = slab_test(ld3(p), ld3(p + 3), oo, od, t_max);
+                break;
+            }
+            case PBRS_SHAPE_DISK: {
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(disks);
+                occ = disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od);
+                break;
+            }
+            case PBRS_SHAPE_TRIANGLE: {
+                const float* p = S.shapes[in.shape_index].p;
+                CNT(triangles);
+                occ = tri_pred(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
+                break;
+            }
+            default: {
+                pbrs_mesh mesh = S.meshes[in.shape_index];
+                occ = blas_any<STATS>(S, mesh, oo, od, t_max, stk, sp, cnt);
+                break;
+            }
+        }
+        if (occ) return true;
+    }
+    return false;
+}
+
+// Rebuilds the reference's world-space Interaction for the winning primitive: the object-space
+// Interaction of the shape, then AffineTransform::apply (geometry/src/transform.rs:309-320).
+PD Isect reconstruct_isect(const DevScene& S, const Hit& h, f3 o, f3 d) {
+    const pbrs_instance& in = S.inst[h.inst];
+    f3 oo = xf_apply(in.inv, o, 1.0f);
+    f3 od = xf_apply(in.inv, d, 0.0f);
+    Isect li;
+    switch (in.shape_kind) {
+        case PBRS_SHAPE_SPHERE: {
+            const float* p = S.shapes[in.shape_index].p;
+            li = sphere_isect(ld3(p), p[3], oo, od, h.t);
+            break;
+        }
+        case PBRS_SHAPE_QUAD: {
+            const float* p = S.shapes[in.shape_index].p;
+            li = quad_isect(ld3(p), ld3(p + 3), ld3(p + 6), oo, od);
+            break;
+        }
+        case PBRS_SHAPE_CUBOID: {
+            const float* p = S.shapes[in.shape_index].p;
+            li = cuboid_isect(ld3(p), ld3(p + 3), oo, od);
+            break;
+        }
+        case PBRS_SHAPE_DISK: {
+            const float* p = S.shapes[in.shape_index].p;
+            li = disk_isect(ld3(p), ld3(p + 3), oo, od, h.t);
+            break;
+        }
+        case PBRS_SHAPE_TRIANGLE: {  // simple.rs:425-427
+            const float* p = S.shapes[in.shape_index].p;
+            f3 p0 = ld3(p), p1 = ld3(p + 3), p2 = ld3(p + 6);
+            TriHit th;
+            tri_hit(p0, p1, p2, oo, od, pn_inf(), th);
+            li.pos = bary_lerp(p0, p1, p2, th.b0, th.b1);
+            li.normal = th.normal;
+            li.wo = -od;
+            li.tangent = with_dpdu(th.normal, p1 - p0);
+            break;
+        }
+        default: {
+            pbrs_tri_verts tv = load_tri(S.tv + h.prim);
+            f3 p0 = ld3(tv.p0), p1 = ld3(tv.p1), p2 = ld3(tv.p2);
+            TriHit th;
+            tri_hit(p0, p1, p2, oo, od, pn_inf(), th);
+            f3 n, dpdu;
+            mesh_tri_shading(tv, S.ts[h.prim], od, th, n, dpdu);
+            li.pos = bary_lerp(p0, p1, p2, th.b0, th.b1);
+            li.normal = n;
+            li.wo = -od;
+            li.tangent = with_dpdu(n, dpdu);
+            break;
+        }
+    }
+    Isect w;
+    w.pos = xf_apply(in.fwd, li.pos, 1.0f);
+    w.wo = xf_apply(in.fwd, li.wo, 0.0f);
+    w.normal = xf_normal(in.inv, li.normal);
+    w.tangent = with_dpdu(w.normal, xf_apply(in.fwd, li.tangent, 0.0f));
+    return w;
+}

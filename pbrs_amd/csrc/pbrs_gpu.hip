@@ -1,0 +1,585 @@
+// pbrs_gpu.hip — implementation of include/pbrs_gpu.h for gfx950 (MI355X).
+//
+// Host-side driver of the wavefront pipeline in device/kernels.h: owns the HBM copies of the
+// flattened scene, the SoA path state, the slot queues and the per-tile accumulator, and issues
+//     raygen -> [extend -> shade -> shadow] x max_depth -> accumulate
+// per pass of `samples_per_pass` sample indices, all on one HIP stream with no host round trip
+// inside a tile: queue lengths stay on the device (kernels read them; empty blocks exit).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see include/pbrs_numeric.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pbrs_gpu.h"
+#include "device/kernels.h"
+
+namespace {
+
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kMaxDepth = 64;
+constexpr size_t kLdsBytesPerCU = 160 * 1024;
+
+struct StageEvent {
+    int stage;  // 0 raygen, 1 extend, 2 shade, 3 shadow, 4 accumulate
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct pbrs_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    // scene
+    bool has_scene = false;
+    std::vector<void*> scene_allocs;
+    DevScene S{};
+    uint32_t stack_depth = 0;
+
+    // working set
+    size_t cap_slots = 0, cap_pixels = 0;
+    void* state_mem = nullptr;
+    PathState st{};
+    uint32_t* queues = nullptr;   // 3 * cap_slots: ping, pong, shadow
+    uint32_t* counters = nullptr; // 2 * (kMaxDepth + 2)
+    float* sum = nullptr;         // 3 * cap_pixels, planar
+    float* rgb_dev = nullptr;     // 3 * cap_pixels, row-major (for the host-output variant)
+    GlobalCounters* gcnt = nullptr;  // [0] extend, [1] shadow
+
+    // timing
+    std::vector<StageEvent> events;
+    size_t events_used = 0;
+    std::vector<hipEvent_t> total_ev;  // 2
+    pbrs_stats pending{};
+    bool pending_counters = false, pending_times = false;
+    uint64_t pending_closest = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            return PBRS_E_DEVICE;                                                                     \
+        }                                                                                             \
+    } while (0)
+
+int fail(pbrs_ctx* c, int code, const char* msg) {
+    c->error = msg;
+    return code;
+}
+
+template <class T>
+int upload(pbrs_ctx* c, const T* src, size_t n, const T** dst) {
+    *dst = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, bytes));
+    c->scene_allocs.push_back(p);
+    if (n) HIPCHK(c, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T*>(p);
+    return PBRS_OK;
+}
+
+void free_scene(pbrs_ctx* c) {
+    for (void* p : c->scene_allocs) (void)hipFree(p);
+    c->scene_allocs.clear();
+    c->has_scene = false;
+}
+
+void free_work(pbrs_ctx* c) {
+    if (c->state_mem) (void)hipFree(c->state_mem);
+    if (c->queues) (void)hipFree(c->queues);
+    if (c->sum) (void)hipFree(c->sum);
+    if (c->rgb_dev) (void)hipFree(c->rgb_dev);
+    c->state_mem = nullptr;
+    c->queues = nullptr;
+    c->sum = nullptr;
+    c->rgb_dev = nullptr;
+    c->cap_slots = c->cap_pixels = 0;
+}
+
+// Carves the SoA columns out of one allocation; every column starts 256-byte aligned.
+int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
+    if (n_slots > c->cap_slots) {
+        if (c->state_mem) (void)hipFree(c->state_mem);
+        if (c->queues) (void)hipFree(c->queues);
+        c->state_mem = nullptr;
+        c->queues = nullptr;
+        size_t col = ((n_slots * 4 + 255) / 256) * 256;
+        const size_t n_cols = 6 + 3 + 3 + 2 /*rng*/ + 1 + 5 + 18 + 2 + 3 + 1 + 1;
+        HIPCHK(c, hipMalloc(&c->state_mem, col * n_cols));
+        char* base = static_cast<char*>(c->state_mem);
+        size_t k = 0;
+        auto colf = [&]() { return reinterpret_cast<float*>(base + col * (k++)); };
+        auto colu = [&]() { return reinterpret_cast<uint32_t*>(base + col * (k++)); };
+        PathState& s = c->st;
+        s.ox = colf(); s.oy = colf(); s.oz = colf(); s.dx = colf(); s.dy = colf(); s.dz = colf();
+        s.br = colf(); s.bg = colf(); s.bb = colf();
+        s.lr = colf(); s.lg = colf(); s.lb = colf();
+        s.rng = reinterpret_cast<uint64_t*>(base + col * k);
+        k += 2;
+        s.flags = colu();
+        s.ht = colf(); s.hinst = colu(); s.hprim = colu(); s.hb1 = colf(); s.hb2 = colf();
+        for (int r = 0; r < 2; ++r)
+            for (int a = 0; a < 3; ++a) s.so[r][a] = colf();
+        for (int r = 0; r < 2; ++r)
+            for (int a = 0; a < 3; ++a) s.sd[r][a] = colf();
+        for (int r = 0; r < 2; ++r)
+            for (int a = 0; a < 3; ++a) s.sc[r][a] = colf();
+        s.stmax[0] = colf(); s.stmax[1] = colf();
+        for (int a = 0; a < 3; ++a) s.nb[a] = colf();
+        s.nscale = colf();
+        s.nmode = colu();
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->queues), 3 * n_slots * sizeof(uint32_t)));
+        c->cap_slots = n_slots;
+    }
+    if (n_pixels > c->cap_pixels) {
+        if (c->sum) (void)hipFree(c->sum);
+        if (c->rgb_dev) (void)hipFree(c->rgb_dev);
+        c->sum = nullptr;
+        c->rgb_dev = nullptr;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->sum), 3 * n_pixels * sizeof(float)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->rgb_dev), 3 * n_pixels * sizeof(float)));
+        c->cap_pixels = n_pixels;
+    }
+    return PBRS_OK;
+}
+
+size_t lds_bytes(const pbrs_ctx* c) { return (size_t)(c->stack_depth) * kBlock * sizeof(uint32_t); }
+
+int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p) {
+    if (!cam || !p) return fail(c, PBRS_E_INVALID, "null camera or params");
+    if (!c->has_scene) return fail(c, PBRS_E_NO_SCENE, "no scene uploaded");
+    if (p->w == 0 || p->h == 0) return fail(c, PBRS_E_INVALID, "empty tile");
+    if (p->x0 + p->w > cam->width || p->y0 + p->h > cam->height) return fail(c, PBRS_E_INVALID, "tile outside the film");
+    if (p->strata_x == 0 || p->strata_y == 0) return fail(c, PBRS_E_INVALID, "zero strata");
+    if (p->max_depth > kMaxDepth) return fail(c, PBRS_E_LIMIT, "max_depth above 64");
+    if ((uint64_t)p->w * p->h > (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile above 2^28 pixels");
+    return PBRS_OK;
+}
+
+struct Timer {
+    pbrs_ctx* c;
+    bool on;
+    int begin(int stage) {
+        if (!on) return 0;
+        if (c->events_used == c->events.size()) {
+            StageEvent e{};
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return -1;
+            c->events.push_back(e);
+        }
+        StageEvent& e = c->events[c->events_used];
+        e.stage = stage;
+        return hipEventRecord(e.a, c->stream) == hipSuccess ? 0 : -1;
+    }
+    int end() {
+        if (!on) return 0;
+        StageEvent& e = c->events[c->events_used++];
+        return hipEventRecord(e.b, c->stream) == hipSuccess ? 0 : -1;
+    }
+};
+
+RenderConst make_const(const pbrs_camera* cam, const pbrs_render_params* p) {
+    RenderConst rc{};
+    rc.cam = *cam;
+    rc.x0 = p->x0; rc.y0 = p->y0; rc.w = p->w; rc.h = p->h;
+    rc.strata_x = p->strata_x; rc.strata_y = p->strata_y;
+    rc.max_depth = p->max_depth;
+    rc.n_pixels = p->w * p->h;
+    rc.seed = p->seed;
+    return rc;
+}
+
+uint32_t auto_samples_per_pass(const pbrs_render_params* p) {
+    uint64_t P = (uint64_t)p->w * p->h, spp = (uint64_t)p->strata_x * p->strata_y;
+    uint64_t k = p->samples_per_pass;
+    if (k == 0) {
+        const uint64_t target = 4ull << 20;  // ~4M paths in flight: >> 256 CUs x 2048 lanes, < 1 GiB of state
+        k = P >= target ? 1 : target / P;
+    }
+    if (k > spp) k = spp;
+    if (k < 1) k = 1;
+    return (uint32_t)k;
+}
+
+// One pass: kc sample indices starting at `first` for every pixel of the tile.
+int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stats, Timer& tm) {
+    const uint32_t P = rc.n_pixels;
+    const uint32_t N = P * kc;
+    rc.pass_first_sample = first;
+    rc.n_slots = N;
+    const uint32_t grid = (N + kBlock - 1) / kBlock;
+    uint32_t* act = c->counters;                  // act[b]: paths entering bounce b (b >= 1)
+    uint32_t* shc = c->counters + (kMaxDepth + 2);  // shc[b]: paths with pending shadow rays at bounce b
+    uint32_t* q[2] = {c->queues, c->queues + c->cap_slots};
+    uint32_t* shq = c->queues + 2 * c->cap_slots;
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, 2 * (kMaxDepth + 2) * sizeof(uint32_t), c->stream));
+    if (tm.begin(0)) return fail(c, PBRS_E_DEVICE, "event record failed");
+    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, c->st, rc);
+    tm.end();
+    const size_t lds = lds_bytes(c);
+    for (uint32_t b = 0; b < rc.max_depth; ++b) {
+        const uint32_t* qin = b == 0 ? nullptr : q[b & 1];
+        if (tm.begin(1)) return fail(c, PBRS_E_DEVICE, "event record failed");
+        if (stats)
+            hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, c->gcnt);
+        else
+            hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, c->gcnt);
+        tm.end();
+        if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
+        hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], act + b + 1, shq,
+                           shc + b);
+        tm.end();
+        if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
+        if (stats)
+            hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, shc + b, c->gcnt + 1);
+        else
+            hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, shc + b, c->gcnt + 1);
+        tm.end();
+    }
+    if (tm.begin(4)) return fail(c, PBRS_E_DEVICE, "event record failed");
+    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, c->sum, P, kc);
+    tm.end();
+    HIPCHK(c, hipGetLastError());
+    return PBRS_OK;
+}
+
+int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, float* rgb_device) {
+    int rcode = check_params(c, cam, p);
+    if (rcode) return rcode;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t P = p->w * p->h;
+    const uint32_t spp = p->strata_x * p->strata_y;
+    const uint32_t K = auto_samples_per_pass(p);
+    rcode = ensure_work(c, (size_t)P * K, P);
+    if (rcode) return rcode;
+    RenderConst rc = make_const(cam, p);
+    const bool stats = p->collect_counters != 0;
+    Timer tm{c, p->time_stages != 0};
+    c->events_used = 0;
+    c->pending = pbrs_stats{};
+    c->pending_counters = stats;
+    c->pending_times = p->time_stages != 0;
+    c->pending.samples = (uint64_t)P * spp;
+    if (stats) HIPCHK(c, hipMemsetAsync(c->gcnt, 0, 2 * sizeof(GlobalCounters), c->stream));
+    if (c->pending_times) HIPCHK(c, hipEventRecord(c->total_ev[0], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->sum, 0, 3 * (size_t)P * sizeof(float), c->stream));
+    uint32_t passes = 0;
+    for (uint32_t first = 0; first < spp; first += K) {
+        uint32_t kc = spp - first < K ? spp - first : K;
+        rcode = run_pass(c, rc, first, kc, stats, tm);
+        if (rcode) return rcode;
+        ++passes;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->sum, rgb_device, P, 1.0f / (float)spp);
+    if (c->pending_times) HIPCHK(c, hipEventRecord(c->total_ev[1], c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->pending.passes = passes;
+    c->pending.launches_extend = c->pending.launches_shade = c->pending.launches_shadow = passes * p->max_depth;
+    return PBRS_OK;
+}
+
+int collect(pbrs_ctx* c, pbrs_stats* out) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    pbrs_stats s = c->pending;
+    if (c->pending_counters) {
+        GlobalCounters g[2];
+        HIPCHK(c, hipMemcpy(g, c->gcnt, sizeof g, hipMemcpyDeviceToHost));
+        s.closest_rays = g[0].rays;
+        s.shade_events = g[0].hits;
+        s.tlas_nodes = g[0].tlas_nodes; s.blas_nodes = g[0].blas_nodes; s.instances = g[0].instances;
+        s.instance_hits = g[0].instance_hits; s.triangles = g[0].triangles; s.tri_shading = g[0].tri_shading;
+        s.spheres = g[0].spheres; s.quads = g[0].quads; s.cuboids = g[0].cuboids; s.disks = g[0].disks;
+        s.shadow_rays = g[1].rays;
+        s.shadow_tlas_nodes = g[1].tlas_nodes; s.shadow_blas_nodes = g[1].blas_nodes; s.shadow_instances = g[1].instances;
+        s.shadow_triangles = g[1].triangles;
+        s.shadow_prims = g[1].spheres + g[1].quads + g[1].cuboids + g[1].disks;
+    }
+    if (c->pending_times) {
+        float* acc[5] = {&s.ms_raygen, &s.ms_extend, &s.ms_shade, &s.ms_shadow, &s.ms_accumulate};
+        for (size_t i = 0; i < c->events_used; ++i) {
+            float ms = 0.0f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b));
+            *acc[c->events[i].stage] += ms;
+        }
+        HIPCHK(c, hipEventElapsedTime(&s.ms_total, c->total_ev[0], c->total_ev[1]));
+    }
+    if (out) *out = s;
+    return PBRS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pbrs_create(int device_ordinal, pbrs_ctx** out) {
+    if (!out) return PBRS_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return PBRS_E_DEVICE;
+    pbrs_ctx* c = new pbrs_ctx();
+    c->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+        delete c;
+        return PBRS_E_DEVICE;
+    }
+    c->stream = c->own_stream;
+    c->total_ev.resize(2);
+    if (hipEventCreate(&c->total_ev[0]) != hipSuccess || hipEventCreate(&c->total_ev[1]) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->counters), 2 * (kMaxDepth + 2) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) != hipSuccess) {
+        delete c;
+        return PBRS_E_DEVICE;
+    }
+    *out = c;
+    return PBRS_OK;
+}
+
+void pbrs_destroy(pbrs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_work(c);
+    if (c->counters) (void)hipFree(c->counters);
+    if (c->gcnt) (void)hipFree(c->gcnt);
+    for (auto& e : c->events) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    for (auto& e : c->total_ev) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* pbrs_last_error(const pbrs_ctx* c) { return c ? c->error.c_str() : "null context"; }
+
+int pbrs_set_stream(pbrs_ctx* c, void* hip_stream) {
+    if (!c) return PBRS_E_INVALID;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return PBRS_OK;
+}
+
+int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
+    if (!c || !d) return PBRS_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (d->n_tlas_nodes == 0 || d->n_instances == 0) return fail(c, PBRS_E_INVALID, "scene without instances");
+    // Host-side shape checks: every index the kernels dereference must be in range before any launch.
+    for (uint32_t i = 0; i < d->n_tlas_nodes; ++i) {
+        const pbrs_node& n = d->tlas_nodes[i];
+        if (n.b & PBRS_LEAF_FLAG) {
+            if (n.a >= d->n_instances) return fail(c, PBRS_E_INVALID, "tlas leaf references a missing instance");
+        } else if (n.a >= d->n_tlas_nodes || i + 1 >= d->n_tlas_nodes) {
+            return fail(c, PBRS_E_INVALID, "tlas child out of range");
+        }
+    }
+    for (uint32_t i = 0; i < d->n_blas_nodes; ++i) {
+        const pbrs_node& n = d->blas_nodes[i];
+        if (n.b & PBRS_LEAF_FLAG) {
+            uint32_t cnt = n.b & ~PBRS_LEAF_FLAG;
+            if ((uint64_t)n.a + cnt > d->n_triangles) return fail(c, PBRS_E_INVALID, "blas leaf range out of range");
+        } else if (n.a >= d->n_blas_nodes || i + 1 >= d->n_blas_nodes || (n.b & 3u) > 2u) {
+            return fail(c, PBRS_E_INVALID, "blas child out of range");
+        }
+    }
+    uint32_t max_blas_height = 0;
+    for (uint32_t i = 0; i < d->n_meshes; ++i) {
+        if (d->meshes[i].root >= d->n_blas_nodes) return fail(c, PBRS_E_INVALID, "mesh root out of range");
+        if (d->meshes[i].height > max_blas_height) max_blas_height = d->meshes[i].height;
+    }
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+        const pbrs_instance& in = d->instances[i];
+        if (in.material >= d->n_materials) return fail(c, PBRS_E_INVALID, "instance material out of range");
+        if (in.shape_kind > PBRS_SHAPE_MESH) return fail(c, PBRS_E_INVALID, "unknown shape kind");
+        if (in.shape_kind == PBRS_SHAPE_MESH ? in.shape_index >= d->n_meshes : in.shape_index >= d->n_shapes)
+            return fail(c, PBRS_E_INVALID, "instance shape out of range");
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const pbrs_material& m = d->materials[i];
+        if (m.n_bxdfs > PBRS_MAX_BXDFS || (uint64_t)m.first_bxdf + m.n_bxdfs > d->n_bxdfs) return fail(c, PBRS_E_INVALID, "material lobes out of range");
+    }
+    for (uint32_t i = 0; i < d->n_area_lights; ++i) {
+        uint32_t k = d->area_lights[i].shape_kind;
+        if (!(k == PBRS_SHAPE_SPHERE || k == PBRS_SHAPE_DISK || k == PBRS_SHAPE_TRIANGLE || k == PBRS_SHAPE_QUAD))
+            return fail(c, PBRS_E_INVALID, "area light shape kind");
+    }
+    // pending entries never exceed one sibling per level of each tree, plus the node being expanded
+    uint32_t depth = d->tlas_height + max_blas_height + 2;
+    if ((size_t)depth * kBlock * sizeof(uint32_t) > kLdsBytesPerCU / 2) return fail(c, PBRS_E_LIMIT, "traversal stack exceeds the LDS budget");
+    (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    DevScene S{};
+    int rc;
+    if ((rc = upload(c, d->tlas_nodes, d->n_tlas_nodes, &S.tlas))) return rc;
+    if ((rc = upload(c, d->instances, d->n_instances, &S.inst))) return rc;
+    if ((rc = upload(c, d->shapes, d->n_shapes, &S.shapes))) return rc;
+    if ((rc = upload(c, d->meshes, d->n_meshes, &S.meshes))) return rc;
+    if ((rc = upload(c, d->blas_nodes, d->n_blas_nodes, &S.blas))) return rc;
+    if ((rc = upload(c, d->tri_verts, d->n_triangles, &S.tv))) return rc;
+    if ((rc = upload(c, d->tri_shade, d->n_triangles, &S.ts))) return rc;
+    if ((rc = upload(c, d->materials, d->n_materials, &S.mats))) return rc;
+    if ((rc = upload(c, d->bxdfs, d->n_bxdfs, &S.bxdfs))) return rc;
+    if ((rc = upload(c, d->area_lights, d->n_area_lights, &S.alights))) return rc;
+    if ((rc = upload(c, d->delta_lights, d->n_delta_lights, &S.dlights))) return rc;
+    S.n_area = d->n_area_lights;
+    S.n_delta = d->n_delta_lights;
+    std::memcpy(S.env, d->env_constant, sizeof S.env);
+    // Scene::has_env_light for EnvLight::Constant (scene/src/lib.rs:96-102): !c.is_black()
+    S.has_env = !(S.env[0] <= 0.0f && S.env[1] <= 0.0f && S.env[2] <= 0.0f) ? 1u : 0u;
+    c->S = S;
+    c->stack_depth = depth;
+    c->has_scene = true;
+    size_t lds = lds_bytes(c);
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shadow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shadow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect_rays), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return PBRS_OK;
+}
+
+int pbrs_render_tile_device(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, float* rgb_out_device, pbrs_stats* stats_out) {
+    if (!c) return PBRS_E_INVALID;
+    if (!rgb_out_device) return fail(c, PBRS_E_INVALID, "null output");
+    int rc = render_common(c, cam, p, rgb_out_device);
+    if (rc) return rc;
+    if (stats_out) return collect(c, stats_out);
+    return PBRS_OK;
+}
+
+int pbrs_render_tile(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, float* rgb_out_host, pbrs_stats* stats_out) {
+    if (!c) return PBRS_E_INVALID;
+    if (!rgb_out_host) return fail(c, PBRS_E_INVALID, "null output");
+    int rc = check_params(c, cam, p);
+    if (rc) return rc;
+    rc = ensure_work(c, (size_t)p->w * p->h * auto_samples_per_pass(p), (size_t)p->w * p->h);
+    if (rc) return rc;
+    rc = render_common(c, cam, p, c->rgb_dev);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(rgb_out_host, c->rgb_dev, 3 * (size_t)p->w * p->h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return collect(c, stats_out);
+}
+
+int pbrs_collect_stats(pbrs_ctx* c, pbrs_stats* stats_out) {
+    if (!c) return PBRS_E_INVALID;
+    return collect(c, stats_out);
+}
+
+int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const float* dirs, const float* tmax, pbrs_hit_record* hits_out,
+                        uint8_t* occluded_out) {
+    if (!c) return PBRS_E_INVALID;
+    if (!c->has_scene) return fail(c, PBRS_E_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PBRS_OK;
+    if (!origins || !dirs || !tmax) return fail(c, PBRS_E_INVALID, "null ray arrays");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    pbrs_hit_record* d_h = nullptr;
+    uint8_t* d_occ = nullptr;
+    int rc = PBRS_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_h); (void)hipFree(d_occ);
+    };
+#define TRY(expr)                                                                  \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            c->error = std::string(#expr) + ": " + hipGetErrorString(e_);          \
+            cleanup();                                                             \
+            return PBRS_E_DEVICE;                                                  \
+        }                                                                          \
+    } while (0)
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_o), (size_t)n * 12));
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_d), (size_t)n * 12));
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_t), (size_t)n * 4));
+    if (hits_out) TRY(hipMalloc(reinterpret_cast<void**>(&d_h), (size_t)n * sizeof(pbrs_hit_record)));
+    if (occluded_out) TRY(hipMalloc(reinterpret_cast<void**>(&d_occ), (size_t)n));
+    TRY(hipMemcpyAsync(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemcpyAsync(d_d, dirs, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemcpyAsync(d_t, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_intersect_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds_bytes(c), c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ);
+    TRY(hipGetLastError());
+    if (hits_out) TRY(hipMemcpyAsync(hits_out, d_h, (size_t)n * sizeof(pbrs_hit_record), hipMemcpyDeviceToHost, c->stream));
+    if (occluded_out) TRY(hipMemcpyAsync(occluded_out, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipStreamSynchronize(c->stream));
+    cleanup();
+    return rc;
+}
+
+int pbrs_camera_rays(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, uint32_t sample_index, float* origins_out, float* dirs_out) {
+    if (!c) return PBRS_E_INVALID;
+    int rc = check_params(c, cam, p);
+    if (rc) return rc;
+    if (!origins_out || !dirs_out) return fail(c, PBRS_E_INVALID, "null output");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t P = p->w * p->h;
+    rc = ensure_work(c, P, P);
+    if (rc) return rc;
+    RenderConst k = make_const(cam, p);
+    k.pass_first_sample = sample_index;
+    k.n_slots = P;
+    hipLaunchKernelGGL(k_raygen, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, k);
+    float *d_o = nullptr, *d_d = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); };
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_o), (size_t)P * 12));
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_d), (size_t)P * 12));
+    hipLaunchKernelGGL(k_export_rays, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, P, d_o, d_d);
+    TRY(hipGetLastError());
+    TRY(hipMemcpyAsync(origins_out, d_o, (size_t)P * 12, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipMemcpyAsync(dirs_out, d_d, (size_t)P * 12, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipStreamSynchronize(c->stream));
+    cleanup();
+    return PBRS_OK;
+}
+
+int pbrs_numeric_eval(pbrs_ctx* c, uint32_t fn, uint32_t n, const float* x, const float* y, float* out) {
+    if (!c) return PBRS_E_INVALID;
+    if (n == 0) return PBRS_OK;
+    if (!x || !out || fn > 14) return fail(c, PBRS_E_INVALID, "bad numeric_eval arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d_x = nullptr, *d_y = nullptr, *d_r = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_r); };
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_x), (size_t)n * 4));
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_r), (size_t)n * 4));
+    TRY(hipMemcpyAsync(d_x, x, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (y) {
+        TRY(hipMalloc(reinterpret_cast<void**>(&d_y), (size_t)n * 4));
+        TRY(hipMemcpyAsync(d_y, y, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(k_numeric_eval, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, fn, n, d_x, d_y, d_r);
+    TRY(hipGetLastError());
+    TRY(hipMemcpyAsync(out, d_r, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipStreamSynchronize(c->stream));
+    cleanup();
+    return PBRS_OK;
+}
+
+int pbrs_render_sample_radiance(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, uint32_t sample_index, float* rgb_out_host) {
+    if (!c) return PBRS_E_INVALID;
+    int rc = check_params(c, cam, p);
+    if (rc) return rc;
+    if (!rgb_out_host) return fail(c, PBRS_E_INVALID, "null output");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t P = p->w * p->h;
+    rc = ensure_work(c, P, P);
+    if (rc) return rc;
+    RenderConst k = make_const(cam, p);
+    Timer tm{c, false};
+    HIPCHK(c, hipMemsetAsync(c->sum, 0, 3 * (size_t)P * sizeof(float), c->stream));
+    rc = run_pass(c, k, sample_index, 1, false, tm);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_export_radiance, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, P, c->rgb_dev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(rgb_out_host, c->rgb_dev, 3 * (size_t)P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PBRS_OK;
+}
+
+}  // extern "C"

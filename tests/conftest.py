@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import binding
+    return binding.lib()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import pbrs_amd
+    ctx = pbrs_amd.Context(0)
+    yield ctx
+    ctx.close()
