@@ -213,6 +213,12 @@ typedef struct pbrs_render_params {
     uint64_t seed;                 /* RNG contract, include/pbrs_numeric.h                          */
     uint32_t collect_counters;     /* run the instrumented kernels and fill the work counters      */
     uint32_t time_stages;          /* bracket every launch with HIP events and fill ms_*           */
+    /* Interleaved row bands, the multi-GPU partition of the rayon row loop (src/main.rs:219-224):
+     * with band_count > 1 the tile's h rows are the rows of bands band_index, band_index+band_count, ...
+     * (band_rows rows each) counted from y0, packed:  film_row = y0 + ((r / band_rows) * band_count
+     * + band_index) * band_rows + r % band_rows.  band_count <= 1 means a plain rectangular tile. */
+    uint32_t band_rows, band_count, band_index;
+    uint32_t pad;
 } pbrs_render_params;
 
 /* Renders a tile; replaces src/main.rs:192-231 for the rows/cols of the tile.  `rgb_out` is

@@ -54,7 +54,7 @@ def lib():
         L.oracle_tlas_height.argtypes = [C.c_void_p]
         L.oracle_render_tile.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.oracle_trace_sample.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_uint64, C.c_void_p]
-        L.oracle_intersect_rays.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        L.oracle_intersect_rays.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
         L.oracle_camera_rays.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_void_p, C.c_void_p]
         L.oracle_numeric_eval.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_rng_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -135,6 +135,10 @@ class OracleScene:
         hits = np.empty(n, dtype=HIT_DTYPE) if closest else None
         occ = np.empty(n, dtype=np.uint8) if anyhit else None
         st = Stats()
+        ties = np.zeros(n, dtype=np.uint8)  # per ray: tlas/src/bvh.rs:94 saw equal t on both sides
         lib().oracle_intersect_rays(self._h, n, origins.ctypes.data, dirs.ctypes.data, tmax.ctypes.data,
-                                    hits.ctypes.data if closest else None, occ.ctypes.data if anyhit else None, C.addressof(st))
-        return hits, occ, st.as_dict()
+                                    hits.ctypes.data if closest else None, occ.ctypes.data if anyhit else None, C.addressof(st),
+                                    ties.ctypes.data)
+        d = st.as_dict()
+        d["tie_mask"] = ties.astype(bool)
+        return hits, occ, d

@@ -58,7 +58,7 @@ int oracle_render_tile(const oracle_scene*, uint32_t x0, uint32_t y0, uint32_t w
 int oracle_trace_sample(const oracle_scene*, uint32_t row, uint32_t col, uint32_t sample_index, uint32_t strata_x, uint32_t strata_y,
                         uint32_t max_depth, uint64_t seed, oracle_path_trace* trace);
 int oracle_intersect_rays(const oracle_scene*, uint32_t n, const float* origins, const float* dirs, const float* tmax,
-                          oracle_hit_record* hits_out, uint8_t* occluded_out, oracle_stats* stats_out);
+                          oracle_hit_record* hits_out, uint8_t* occluded_out, oracle_stats* stats_out, uint8_t* tie_out);
 int oracle_camera_rays(const oracle_scene*, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t sample_index, uint32_t strata_x,
                        uint32_t strata_y, uint64_t seed, float* origins, float* dirs);
 int oracle_numeric_eval(uint32_t fn, uint32_t n, const float* x, const float* y, float* out);

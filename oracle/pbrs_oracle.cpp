@@ -375,7 +375,7 @@ int oracle_trace_sample(const oracle_scene* os, uint32_t row, uint32_t col, uint
 // Closest hit / any hit for caller-supplied rays (tlas/src/bvh.rs:77-113): the `extend` / `shadow`
 // kernel parity harness.  hits_out: n records of {t, inst, prim, b1, b2} (inst = 0xffffffff on a miss).
 int oracle_intersect_rays(const oracle_scene* os, uint32_t n, const float* origins, const float* dirs, const float* tmax,
-                          oracle_hit_record* hits_out, uint8_t* occluded_out, oracle_stats* stats_out) {
+                          oracle_hit_record* hits_out, uint8_t* occluded_out, oracle_stats* stats_out, uint8_t* tie_out) {
     const Scene& scene = *os->scene;
     Counters c;
     Diag d;
@@ -387,7 +387,10 @@ int oracle_intersect_rays(const oracle_scene* os, uint32_t n, const float* origi
             Ray rm = r;
             Hit h;
             c.closest_rays++;
-            if (scene.tlas->intersect(rm, &h)) {
+            uint64_t ties_before = d.tlas_ties;
+            bool found = scene.tlas->intersect(rm, &h);
+            if (tie_out) tie_out[i] = d.tlas_ties != ties_before ? 1 : 0;
+            if (found) {
                 hits_out[i].t = h.isect.ray_t;
                 hits_out[i].inst = h.inst->index;
                 hits_out[i].prim = h.isect.prim;

@@ -59,7 +59,8 @@ class Stats(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32), ("strata_x", C.c_uint32),
                 ("strata_y", C.c_uint32), ("max_depth", C.c_uint32), ("samples_per_pass", C.c_uint32), ("seed", C.c_uint64),
-                ("collect_counters", C.c_uint32), ("time_stages", C.c_uint32)]
+                ("collect_counters", C.c_uint32), ("time_stages", C.c_uint32),
+                ("band_rows", C.c_uint32), ("band_count", C.c_uint32), ("band_index", C.c_uint32), ("pad", C.c_uint32)]
 
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("inst", np.uint32), ("prim", np.uint32), ("b1", np.float32), ("b2", np.float32)])
@@ -146,6 +147,8 @@ class HostScene:
 
     def nodes(self, which="tlas"):
         n, p = (self.desc.n_tlas_nodes, self.desc.tlas_nodes) if which == "tlas" else (self.desc.n_blas_nodes, self.desc.blas_nodes)
+        if n == 0 or not p:
+            return np.zeros((0, 8), dtype=np.uint32)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n, 8)).copy()
 
     def close(self):
@@ -188,17 +191,20 @@ class Context:
         self._check(self._L.pbrs_upload_scene(self._h, C.addressof(host_scene.desc)), "pbrs_upload_scene")
         self.scene = host_scene
 
-    def _params(self, strata_x, strata_y, depth, seed, tile, samples_per_pass=0, counters=False, timing=False):
+    def _params(self, strata_x, strata_y, depth, seed, tile, samples_per_pass=0, counters=False, timing=False, bands=None):
         x0, y0, w, h = tile or (0, 0, self.scene.width, self.scene.height)
         p = RenderParams()
+        if bands:
+            p.band_rows, p.band_count, p.band_index = bands
         p.x0, p.y0, p.w, p.h = x0, y0, w, h
         p.strata_x, p.strata_y, p.max_depth, p.samples_per_pass = strata_x, strata_y, depth, samples_per_pass
         p.seed, p.collect_counters, p.time_stages = seed, int(counters), int(timing)
         return p
 
-    def render(self, strata_x, strata_y, depth, seed, tile=None, samples_per_pass=0, counters=False, timing=False):
-        """-> (h, w, 3) f32 radiance, stats dict.  Host output (one D2H copy at the end)."""
-        p = self._params(strata_x, strata_y, depth, seed, tile, samples_per_pass, counters, timing)
+    def render(self, strata_x, strata_y, depth, seed, tile=None, samples_per_pass=0, counters=False, timing=False, bands=None):
+        """-> (h, w, 3) f32 radiance, stats dict.  Host output (one D2H copy at the end).
+        bands = (band_rows, band_count, band_index): the tile's rows are interleaved row bands."""
+        p = self._params(strata_x, strata_y, depth, seed, tile, samples_per_pass, counters, timing, bands)
         out = np.empty((p.h, p.w, 3), dtype=np.float32)
         st = Stats()
         self._check(self._L.pbrs_render_tile(self._h, C.addressof(self.scene.camera), C.addressof(p), out.ctypes.data, C.addressof(st)),
@@ -206,9 +212,9 @@ class Context:
         return out, st.as_dict()
 
     def render_device(self, rgb_device_ptr, strata_x, strata_y, depth, seed, tile=None, samples_per_pass=0, counters=False,
-                      timing=False):
+                      timing=False, bands=None):
         """Asynchronous: the result lands in caller-owned device memory on the context's stream."""
-        p = self._params(strata_x, strata_y, depth, seed, tile, samples_per_pass, counters, timing)
+        p = self._params(strata_x, strata_y, depth, seed, tile, samples_per_pass, counters, timing, bands)
         self._check(self._L.pbrs_render_tile_device(self._h, C.addressof(self.scene.camera), C.addressof(p), C.c_void_p(rgb_device_ptr), None),
                     "pbrs_render_tile_device")
 

@@ -42,6 +42,7 @@ struct RenderConst {
     uint32_t pass_first_sample;  // sample index of k = 0 in this pass
     uint32_t n_pixels;           // P
     uint32_t n_slots;            // P * K of this pass
+    uint32_t band_rows, band_count, band_index;  // interleaved row bands (pbrs_render_params)
     uint64_t seed;
 };
 
@@ -72,7 +73,8 @@ __global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= rc.n_slots) return;
     uint32_t k = slot / rc.n_pixels, pix = slot - k * rc.n_pixels;
-    uint32_t col = rc.x0 + pix % rc.w, row = rc.y0 + pix / rc.w;
+    uint32_t col = rc.x0 + pix % rc.w, vrow = pix / rc.w;
+    uint32_t row = rc.y0 + (rc.band_count > 1 ? ((vrow / rc.band_rows) * rc.band_count + rc.band_index) * rc.band_rows + vrow % rc.band_rows : vrow);
     uint32_t i = rc.pass_first_sample + k;
     uint64_t rng = pn_rng_init(rc.seed, row * rc.cam.width + col, i);
     float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);

@@ -159,7 +159,14 @@ int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* 
     if (!cam || !p) return fail(c, PBRS_E_INVALID, "null camera or params");
     if (!c->has_scene) return fail(c, PBRS_E_NO_SCENE, "no scene uploaded");
     if (p->w == 0 || p->h == 0) return fail(c, PBRS_E_INVALID, "empty tile");
-    if (p->x0 + p->w > cam->width || p->y0 + p->h > cam->height) return fail(c, PBRS_E_INVALID, "tile outside the film");
+    if (p->band_count > 1) {
+        if (p->band_rows == 0 || p->band_index >= p->band_count) return fail(c, PBRS_E_INVALID, "bad row-band parameters");
+        uint64_t vr = p->h - 1;
+        uint64_t last = p->y0 + ((vr / p->band_rows) * p->band_count + p->band_index) * (uint64_t)p->band_rows + vr % p->band_rows;
+        if (p->x0 + p->w > cam->width || last >= cam->height) return fail(c, PBRS_E_INVALID, "row bands outside the film");
+    } else if (p->x0 + p->w > cam->width || p->y0 + p->h > cam->height) {
+        return fail(c, PBRS_E_INVALID, "tile outside the film");
+    }
     if (p->strata_x == 0 || p->strata_y == 0) return fail(c, PBRS_E_INVALID, "zero strata");
     if (p->max_depth > kMaxDepth) return fail(c, PBRS_E_LIMIT, "max_depth above 64");
     if ((uint64_t)p->w * p->h > (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile above 2^28 pixels");
@@ -194,6 +201,7 @@ RenderConst make_const(const pbrs_camera* cam, const pbrs_render_params* p) {
     rc.strata_x = p->strata_x; rc.strata_y = p->strata_y;
     rc.max_depth = p->max_depth;
     rc.n_pixels = p->w * p->h;
+    rc.band_rows = p->band_rows; rc.band_count = p->band_count; rc.band_index = p->band_index;
     rc.seed = p->seed;
     return rc;
 }

@@ -1,0 +1,178 @@
+"""Whole hot path (raygen -> extend -> shade -> shadow -> accumulate) through pbrs_render_tile against the oracle,
+the committed fixtures, and size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: BASELINE.json asks per-pixel L2 radiance error < 1e-4 vs the CPU reference at matched seeds.  The f32
+contract (include/pbrs_numeric.h, -ffp-contract=off, IEEE divide/sqrt) makes the two paths agree bit for bit, so
+the tests assert equality of the bit patterns and report the L2 bound as the fallback criterion."""
+import numpy as np
+import pytest
+
+import pbrs_amd
+from common import GOLDEN_NAMES, SEED, bits, golden_case, load_golden
+from oracle.binding import OracleScene
+from pbrs_amd import scenes, tiling
+
+pytestmark = pytest.mark.gpu
+L2_TOL = 1e-4
+
+
+def l2(a, b):
+    return float(np.sqrt(((a.astype(np.float64) - b.astype(np.float64)) ** 2).sum(axis=-1)).max())
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_image_matches_golden_and_counters(gpu_ctx, name):
+    g = load_golden(name)
+    sb, (w, h, sx, sy, depth) = golden_case(name)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    img, st = gpu_ctx.render(sx, sy, depth, SEED, counters=True)
+    assert l2(img, g["image"]) < L2_TOL
+    assert (bits(img) == bits(g["image"])).all(), "radiance differs in the last bits from the oracle fixture"
+    want = dict(zip(list(g["counter_names"]), g["counters"].tolist()))
+    # identical traversal => identical work counts (the oracle lumps closest + shadow traversal together)
+    assert st["closest_rays"] == want["closest_rays"] and st["shadow_rays"] == want["shadow_rays"]
+    assert st["shade_events"] == want["shade_events"] and st["samples"] == want["samples"]
+    assert st["tlas_nodes"] + st["shadow_tlas_nodes"] == want["tlas_nodes"]
+    assert st["blas_nodes"] + st["shadow_blas_nodes"] == want["blas_nodes"]
+    assert st["triangles"] + st["shadow_triangles"] == want["triangles"]
+    assert st["tri_shading"] == want["tri_shading"]
+
+
+@pytest.mark.parametrize("cfg,w,h,sx,sy,depth,kw", [
+    ("c1", 128, 128, 4, 4, 4, {}),
+    ("c2", 96, 96, 3, 3, 8, {}),
+    ("c3", 96, 96, 3, 3, 8, {}),
+    ("c3", 64, 64, 2, 2, 12, {}),   # deeper than BASELINE: Russian roulette over many bounces
+    ("c4", 80, 45, 4, 2, 8, {"nx": 96, "nz": 160}),  # non-square strata (32x16 at full size)
+    ("c5", 96, 54, 2, 2, 8, {}),
+])
+def test_image_matches_oracle(gpu_ctx, cfg, w, h, sx, sy, depth, kw):
+    sb, _ = scenes.build_config(cfg, width=w, height=h, **kw)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    img, _ = gpu_ctx.render(sx, sy, depth, 7)
+    ref, ost = OracleScene(sb).render(sx, sy, depth, 7)
+    assert ost["panics"] == 0 and ost["tlas_ties"] == 0
+    assert l2(img, ref) < L2_TOL
+    assert (bits(img) == bits(ref)).all()
+
+
+def test_materials_and_lights_outside_the_baseline_scenes(gpu_ctx):
+    """Uber (5 lobes, swap_remove order), Substrate, Glossy, anisotropic Beckmann, point + distant lights (Q6 guard),
+    disk + quad area lights, constant environment."""
+    from pbrs_amd.spec import SceneBuilder, Transform, deg
+    for variant in range(3):
+        sb = SceneBuilder()
+        floor = sb.substrate((0.4, 0.5, 0.3), (0.1, 0.1, 0.1))
+        sb.instance(scenes.quad_mesh(sb, (-8, 0, -8), (8, 0, -8), (-8, 0, 8), (8, 0, 8), (0, 1, 0)), floor)
+        uber = sb.uber((0.3, 0.2, 0.1), (0.4, 0.4, 0.4), kr=(0.5, 0.5, 0.5), kt=(0.3, 0.3, 0.3), rough=(0.05, 0.2), eta=1.4, opacity=0.7)
+        sb.instance(sb.sphere((0, 0, 0), 1.0), uber, Transform.translater((-2.2, 1.0, 0)))
+        sb.instance(sb.sphere((0, 0, 0), 1.0), sb.glossy((0.9, 0.8, 0.7), 0.01), Transform.translater((0, 1.0, 0.5)))
+        sb.instance(sb.cuboid((-0.7, 0, -0.7), (0.7, 1.6, 0.7)), sb.uber((0.5, 0.1, 0.1), (0, 0, 0), rough=(0.3, 0.3), opacity=1.0),
+                    Transform().rotate_y(deg(30)).translate((2.3, 0, 0)))
+        if variant == 0:
+            sb.env = (0.3, 0.4, 0.6)
+            e = (6.0, 5.0, 4.0)
+            disk = sb.disk((0, 5, 0), (0, -1, 0), (1.2, 0, 0))
+            sb.instance(disk, sb.diffuse_light(e))
+            sb.area_light(e, disk)
+        elif variant == 1:
+            sb.point_light((1, 4, -2), (30, 30, 25))
+            sb.distant_light((0.3, -1.0, 0.4), (1.5, 1.5, 1.2), 12.0)
+            e = (4.0, 4.0, 8.0)
+            for k in range(3):  # 2 delta + 3 area: the Q6 guard sends the last two area picks to the env branch
+                s = sb.sphere((-3 + 3 * k, 4.5, 1), 0.4)
+                sb.instance(s, sb.diffuse_light(e))
+                sb.area_light(e, s)
+        else:
+            e = (8.0, 8.0, 8.0)
+            q = sb.quad((-1, 5, -1), (2, 0, 0), (0, 0, 2))
+            sb.area_light(e, q)  # sampled as a light only (a ParallelQuad instance would trip D1)
+            sb.env = (0.05, 0.05, 0.05)
+        sb.set_camera(72, 48, deg(55.0), (0, 2.5, -7), (0, 1, 0))
+        gpu_ctx.upload(pbrs_amd.HostScene(sb))
+        img, _ = gpu_ctx.render(2, 2, 6, 11)
+        ref, ost = OracleScene(sb).render(2, 2, 6, 11)
+        nan_ref, nan_gpu = np.isnan(ref), np.isnan(img)
+        assert (nan_ref == nan_gpu).all(), variant
+        assert (bits(img)[~nan_ref] == bits(ref)[~nan_ref]).all(), variant
+
+
+def test_tiles_passes_and_bands_do_not_change_the_image(gpu_ctx):
+    """The RNG is keyed by film pixel and sample index: any tiling, any samples_per_pass and any GPU count give
+    the same bits (the multi-GPU correctness argument)."""
+    sb, _ = scenes.build_config("c3", width=64, height=48)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    full, _ = gpu_ctx.render(3, 2, 8, 5)
+    for spp_pass in (1, 4, 6):
+        img, _ = gpu_ctx.render(3, 2, 8, 5, samples_per_pass=spp_pass)
+        assert (bits(img) == bits(full)).all()
+    tiles = np.empty_like(full)
+    for (x0, y0, w, h) in ((0, 0, 33, 17), (33, 0, 31, 17), (0, 17, 64, 31)):
+        tiles[y0:y0 + h, x0:x0 + w] = gpu_ctx.render(3, 2, 8, 5, tile=(x0, y0, w, h))[0]
+    assert (bits(tiles) == bits(full)).all()
+    for world in (2, 3, 8):
+        shares = [tiling.render_share(lambda tile, bands: gpu_ctx.render(3, 2, 8, 5, tile=tile, bands=bands)[0], 64, 48, world, r)
+                  for r in range(world)]
+        assert (bits(tiling.assemble(shares, 64, 48, world)) == bits(full)).all()
+
+
+def test_api_errors(gpu_ctx):
+    sb, _ = golden_case("c1_sphere_light")
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    with pytest.raises(pbrs_amd.PbrsError, match="outside the film"):
+        gpu_ctx.render(1, 1, 2, 1, tile=(40, 40, 16, 16))
+    with pytest.raises(pbrs_amd.PbrsError, match="zero strata"):
+        gpu_ctx.render(0, 1, 2, 1)
+    fresh = pbrs_amd.Context(0)
+    fresh.scene = gpu_ctx.scene
+    with pytest.raises(pbrs_amd.PbrsError, match="no scene"):
+        fresh.render(1, 1, 2, 1)
+    fresh.close()
+
+
+# ---- BASELINE.json full sizes: properties that need no CPU reference -------------------------------------------------------------
+
+def test_full_size_c2_properties(gpu_ctx):
+    """Cornell diffuse at 1024x1024 (spp reduced to 16 to keep the test short): determinism, linearity in the
+    emitted radiance (x2 is exact in binary floating point), energy sanity, and agreement of a sub-tile with
+    the oracle."""
+    sb, cfg = scenes.build_config("c2")
+    hs = pbrs_amd.HostScene(sb)
+    gpu_ctx.upload(hs)
+    a, st = gpu_ctx.render(4, 4, cfg["depth"], 1, counters=True)
+    b, _ = gpu_ctx.render(4, 4, cfg["depth"], 1)
+    assert (bits(a) == bits(b)).all()
+    assert np.isfinite(a).all() and (a >= 0).all()
+    assert st["samples"] == 1024 * 1024 * 16 and st["closest_rays"] >= st["samples"]
+    # doubling every emitter doubles every pixel exactly
+    sb2, _ = scenes.build_config("c2")
+    for m in sb2.materials:
+        if m.kind == pbrs_amd.spec.MTL_DIFFUSE_LIGHT:
+            for i in range(3):
+                m.p[i] *= 2.0
+    for al in sb2.area_lights:
+        for i in range(3):
+            al.emit[i] *= 2.0
+    gpu_ctx.upload(pbrs_amd.HostScene(sb2))
+    c, _ = gpu_ctx.render(4, 4, cfg["depth"], 1)
+    assert (bits(c) == bits(a * np.float32(2.0))).all()
+    # a 64x16 window of the full-size frame against the oracle
+    ref, _ = OracleScene(sb).render(4, 4, cfg["depth"], 1, tile=(480, 500, 64, 16))
+    assert (bits(a[500:516, 480:544]) == bits(ref)).all()
+
+
+def test_full_size_c4_million_triangle_window(gpu_ctx):
+    """The 1 048 576-triangle scene at 1920x1080: a 96x8 window at 4 spp against the oracle (deep BLAS, LDS
+    stack depth from the host), and determinism of the same window."""
+    sb, cfg = scenes.build_config("c4")
+    hs = pbrs_amd.HostScene(sb)
+    assert hs.desc.n_triangles == 1048576 + 2
+    gpu_ctx.upload(hs)
+    tile = (900, 600, 96, 8)
+    a, st = gpu_ctx.render(2, 2, cfg["depth"], 1, tile=tile, counters=True)
+    b, _ = gpu_ctx.render(2, 2, cfg["depth"], 1, tile=tile)
+    assert (bits(a) == bits(b)).all()
+    ref, ost = OracleScene(sb).render(2, 2, cfg["depth"], 1, tile=tile)
+    assert ost["panics"] == 0 and ost["tlas_ties"] == 0
+    assert (bits(a) == bits(ref)).all()
+    assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]

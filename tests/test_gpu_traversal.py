@@ -1,0 +1,105 @@
+"""`extend` (closest hit) and `shadow` (any hit) against the oracle's tlas.intersect / tlas.occludes
+(tlas/src/bvh.rs:77-113), through pbrs_intersect_rays / pbrs_camera_rays.  Bit-exact: t, instance, primitive,
+barycentrics, occlusion."""
+import numpy as np
+import pytest
+
+import pbrs_amd
+from common import GOLDEN_NAMES, SEED, bits, golden_case, load_golden
+from oracle.binding import OracleScene
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_hits_equal(h_ref, h_gpu):
+    assert (bits(h_ref["t"]) == bits(h_gpu["t"])).all()
+    assert (h_ref["inst"] == h_gpu["inst"]).all()
+    assert (h_ref["prim"] == h_gpu["prim"]).all()
+    assert (bits(h_ref["b1"]) == bits(h_gpu["b1"])).all() and (bits(h_ref["b2"]) == bits(h_gpu["b2"])).all()
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_camera_rays_and_first_hits_match_golden(gpu_ctx, name):
+    g = load_golden(name)
+    sb, (w, h, sx, sy, depth) = golden_case(name)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    o, d = gpu_ctx.camera_rays(0, sx, sy, SEED)
+    assert (bits(o) == bits(g["ray_o"])).all() and (bits(d) == bits(g["ray_d"])).all()
+    hits, occ = gpu_ctx.intersect(o, d, np.full(len(o), np.inf, dtype=np.float32))
+    assert (bits(hits["t"]) == bits(g["hit_t"])).all()
+    assert (hits["inst"] == g["hit_inst"]).all() and (hits["prim"] == g["hit_prim"]).all()
+    assert (bits(hits["b1"]) == bits(g["hit_b1"])).all() and (bits(hits["b2"]) == bits(g["hit_b2"])).all()
+    assert (occ == g["occluded"]).all()
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_random_rays_match_oracle(gpu_ctx, name):
+    """Rays from random points in random directions with random extents: exercises misses, interior starts,
+    bounded t_max (shadow-ray style) and un-normalised directions."""
+    sb, _ = golden_case(name)
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    rs = np.random.RandomState(5)
+    n = 40000
+    o0, d0 = osc.camera_rays(0, 1, 1, SEED)
+    hits0, _, _ = osc.intersect(o0, d0, np.full(len(o0), np.inf, dtype=np.float32))
+    ok = hits0["inst"] != 0xFFFFFFFF
+    pts = (o0[ok] + d0[ok] * hits0["t"][ok, None]).astype(np.float32)  # points on scene surfaces
+    idx = rs.randint(0, len(pts), n)
+    origins = (pts[idx] + rs.standard_normal((n, 3)) * 0.5 * np.abs(pts).mean()).astype(np.float32)
+    dirs = (rs.standard_normal((n, 3)) * np.exp(rs.uniform(-2, 2, (n, 1)))).astype(np.float32)
+    tmax = np.where(rs.rand(n) < 0.5, np.inf, np.exp(rs.uniform(-3, 6, n))).astype(np.float32)
+    # include exact axis-aligned directions (zero components: the 0/0 and x/0 slab cases, Q21)
+    dirs[:300] = np.eye(3, dtype=np.float32)[rs.randint(0, 3, 300)] * rs.choice([-1.0, 1.0], (300, 1)).astype(np.float32)
+    h_ref, occ_ref, st = osc.intersect(origins, dirs, tmax)
+    h_gpu, occ_gpu = gpu_ctx.intersect(origins, dirs, tmax)
+    # Rays that start inside a Cornell box, or below the floor, can reach the box's bottom face and the
+    # coplanar floor at bit-identical t: the one case where the reference's t_max quirk (a mesh instance
+    # returns hits beyond the ray's extent, shape/src/blas.rs:468) makes the later instance win and the
+    # kernel keeps the earlier one (DESIGN.md "Traversal", documented deviation).  Camera paths never
+    # produce it (tlas_ties == 0 in every render test); these synthetic rays do, rarely.
+    keep = ~st["tie_mask"]
+    assert st["tie_mask"].sum() < n // 200
+    assert (bits(h_ref["t"]) == bits(h_gpu["t"])).all()  # t agrees even on ties; only the instance id may differ
+    assert_hits_equal(h_ref[keep], h_gpu[keep])
+    assert (occ_ref == occ_gpu).all()
+    assert (h_ref["inst"] != 0xFFFFFFFF).sum() > n // 10 and (h_ref["inst"] == 0xFFFFFFFF).sum() > 0
+
+
+def test_every_shape_kind(gpu_ctx):
+    """Sphere, Disk, ParallelQuad (with its D1/D2 defects reproduced), Cuboid, IsolatedTriangle and a mesh in one
+    TLAS under rotated/translated instances."""
+    from pbrs_amd.spec import SceneBuilder, Transform, deg
+    sb = SceneBuilder()
+    m = sb.lambertian((0.5, 0.5, 0.5))
+    sb.instance(sb.sphere((0, 0, 0), 1.0), m, Transform().rotate_y(deg(20)).translate((-4, 0, 0)))
+    sb.instance(sb.disk((0, 0, 0), (0, 0.6, 0.8), (1.5, 0, 0)), m, Transform.translater((-1, 0, 1)))
+    sb.instance(sb.quad((1, -1, 0), (2, 0, 0), (0, 2, 0)), m)
+    sb.instance(sb.cuboid((0, 0, 0), (1, 2, 1)), m, Transform().rotate_y(deg(33)).translate((4.5, -1, 0)))
+    sb.instance(sb.triangle((-1, 2, 0), (1, 2, 0.5), (0, 3.5, 0)), m)
+    sb.instance(sb.mesh([(-3, -3, 2), (3, -3, 2), (-3, -2, 3), (3, -2, 3)], [(0, 0.7, -0.7)] * 4, [(0, 0), (1, 0), (0, 1), (1, 1)],
+                        [(0, 1, 2), (2, 1, 3)]), m, Transform().rotate_x(deg(-10)))
+    sb.set_camera(96, 64, deg(60.0), (0.3, 0.5, -9), (0, 0, 0))
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    o, d = osc.camera_rays(0, 1, 1, 3)
+    tmax = np.full(len(o), np.inf, dtype=np.float32)
+    h_ref, occ_ref, st = osc.intersect(o, d, tmax)
+    h_gpu, occ_gpu = gpu_ctx.intersect(o, d, tmax)
+    assert set(np.unique(h_ref["inst"]).tolist()) >= {0, 1, 2, 3, 4, 5}
+    assert_hits_equal(h_ref, h_gpu)
+    assert (occ_ref == occ_gpu).all()
+
+
+def test_empty_and_degenerate_batches(gpu_ctx):
+    sb, _ = golden_case("c1_sphere_light")
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    hits, occ = gpu_ctx.intersect(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
+    assert len(hits) == 0 and len(occ) == 0
+    # a zero direction: every slab term is 0/0 or x/0; must not hang or fault, and must agree with the oracle
+    o = np.array([[0, 0, -5], [0, 0, 0]], dtype=np.float32)
+    d = np.zeros((2, 3), dtype=np.float32)
+    t = np.full(2, np.inf, dtype=np.float32)
+    h_ref, occ_ref, _ = OracleScene(sb).intersect(o, d, t)
+    h_gpu, occ_gpu = gpu_ctx.intersect(o, d, t)
+    assert (h_ref["inst"] == h_gpu["inst"]).all() and (occ_ref == occ_gpu).all()

@@ -1,0 +1,79 @@
+"""Host flattener (pbrs_amd/csrc/host): tree shape follows the reference's builders and agrees with the oracle's
+independent restatement; flattened records are well-formed.  No GPU needed."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pbrs_amd
+from common import GOLDEN_NAMES, golden_case
+from oracle.binding import OracleScene
+
+LEAF = 0x80000000
+
+
+def node_arrays(hs, which):
+    raw = hs.nodes(which)
+    boxes = raw[:, [0, 1, 2, 4, 5, 6]].copy().view(np.float32)
+    return boxes, raw[:, 3], raw[:, 7]
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_trees_are_well_formed_and_match_the_oracle(name):
+    sb, _ = golden_case(name)
+    hs = pbrs_amd.HostScene(sb)
+    osc = OracleScene(sb)
+    d = hs.desc
+    assert d.tlas_height == osc.tlas_height()
+    assert d.n_tlas_nodes == 2 * d.n_instances - 1  # binary tree with one instance per leaf (tlas/src/bvh.rs:116-152)
+    for which, n_leaf_items in (("tlas", d.n_instances), ("blas", d.n_triangles)):
+        boxes, a, b = node_arrays(hs, which)
+        if len(a) == 0:
+            continue
+        leaf = (b & LEAF) != 0
+        inner = np.nonzero(~leaf)[0]
+        # children of inner nodes are enclosed by the parent (BvhNode::geometric_sound, tlas/src/bvh.rs:62-71)
+        for i in inner:
+            for c in (i + 1, a[i]):
+                assert (boxes[c, :3] >= boxes[i, :3]).all() and (boxes[c, 3:] <= boxes[i, 3:]).all()
+        if which == "blas":
+            counts = (b[leaf] & ~np.uint32(LEAF)).astype(np.int64)
+            assert counts.sum() == n_leaf_items and counts.min() >= 1
+            assert (b[inner] <= 2).all()  # split axis
+            # leaves tile the triangle array without gaps, in pre-order
+            starts = a[leaf].astype(np.int64)
+            assert (np.sort(starts) == np.concatenate([[0], np.cumsum(counts[np.argsort(starts)])[:-1]])).all()
+        else:
+            assert sorted(a[leaf].tolist()) == list(range(d.n_instances))
+
+
+def test_blas_leaf_size_and_height():
+    """recursive_build: leaves hold <= 4 triangles unless the centroids coincide (shape/src/blas.rs:338, :354-360)."""
+    from pbrs_amd import scenes
+    sb, _ = scenes.build_config("c4", width=32, height=32, nx=32, nz=48)
+    hs = pbrs_amd.HostScene(sb)
+    _, a, b = node_arrays(hs, "blas")
+    leaf = (b & LEAF) != 0
+    assert ((b[leaf] & ~np.uint32(LEAF)) <= 4).all()
+    assert hs.stack_depth >= hs.desc.tlas_height + 2
+
+
+def test_q11_vertex_swap_is_baked_in():
+    """`let (i, k, j) = tri.index_triple` (shape/src/blas.rs:162): the flattened triangle reads (v0, v2, v1)."""
+    from pbrs_amd.spec import SceneBuilder, deg
+    sb = SceneBuilder()
+    m = sb.lambertian((0.5, 0.5, 0.5))
+    pos = [(0, 0, 0), (1, 0, 0), (0, 1, 0)]
+    sb.instance(sb.mesh(pos, [(0, 0, 1)] * 3, [(0, 0), (1, 0), (0, 1)], [(0, 1, 2)]), m)
+    sb.set_camera(8, 8, deg(40.0), (0, 0, -5), (0, 0, 0))
+    hs = pbrs_amd.HostScene(sb)
+    tv = np.ctypeslib.as_array(C.cast(hs.desc.tri_verts, C.POINTER(C.c_float)), shape=(1, 12))
+    assert tv[0, 0:3].tolist() == [0, 0, 0] and tv[0, 4:7].tolist() == [0, 1, 0] and tv[0, 8:11].tolist() == [1, 0, 0]
+
+
+def test_rejects_inconsistent_specs():
+    from pbrs_amd.spec import SceneBuilder, deg
+    sb = SceneBuilder()
+    sb.set_camera(8, 8, deg(40.0), (0, 0, -5), (0, 0, 0))
+    with pytest.raises(pbrs_amd.PbrsError, match="empty instances"):
+        pbrs_amd.HostScene(sb)
