@@ -13,6 +13,7 @@
 // the next queue", compacted with __ballot + mbcnt prefix + one atomicAdd per wave.
 #pragma once
 #include "lights.h"
+#include "traverse.h"
 
 struct PathState {
     float *ox, *oy, *oz, *dx, *dy, *dz;  // current ray (t_max is always +inf for path rays: Ray::new)

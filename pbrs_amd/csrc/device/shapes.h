@@ -27,6 +27,7 @@ struct DevScene {
     uint32_t n_area, n_delta;
     float env[3];
     uint32_t has_env;
+    uint32_t fast_slab;  // node coordinates are inside the range the f64-reciprocal box test is exact for (traverse.h)
 };
 
 // Per-lane work counters (instrumented kernel variant only; SURVEY.md §8(d) units).
@@ -324,245 +325,6 @@ struct LaneStack {
     PD void put(int level, uint32_t v) { base[level * stride] = v; }
     PD uint32_t get(int level) const { return base[level * stride]; }
 };
-
-// intersect_bvh (shape/src/blas.rs:422-476) over the flat BLAS, entries pushed above `sp`.
-template <bool STATS>
-PD bool blas_closest(const DevScene& S, const pbrs_mesh& mesh, f3 o, f3 d, float t_max_in, LaneStack stk, int sp, float& out_t, uint32_t& out_prim,
-                     float& out_b1, float& out_b2, Cnt<STATS>& cnt) {
-    const int base = sp;
-    stk.put(sp++, mesh.root);
-    float ray_t_max = t_max_in;  // `let mut ray = r.clone()`
-    float best_t = pn_inf();     // outer_hit.ray_t
-    uint32_t best_prim = 0;
-    float best_b1 = 0.0f, best_b2 = 0.0f;
-    while (sp > base) {
-        uint32_t ni = stk.get(--sp);
-        pbrs_node node = load_node(S.blas + ni);
-        CNT(blas_nodes);
-        if (!slab_test(nmin(node), nmax(node), o, d, ray_t_max)) continue;
-        if (node.b & PBRS_LEAF_FLAG) {
-            uint32_t count = node.b & ~PBRS_LEAF_FLAG;
-            for (uint32_t k = 0; k < count; ++k) {
-                uint32_t ti = node.a + k;
-                pbrs_tri_verts tv = load_tri(S.tv + ti);
-                CNT(triangles);
-                TriHit h;
-                if (!tri_hit(ld3(tv.p0), ld3(tv.p1), ld3(tv.p2), o, d, ray_t_max, h)) continue;
-                CNT(tri_shading);
-                // The reference evaluates the shading frame for every geometric hit (blas.rs:166-206);
-                // only hits that would replace outer_hit can change the result, so only those pay for it.
-                if (!(h.t < best_t)) continue;
-                f3 n, dpdu;
-                if (!mesh_tri_shading(tv, S.ts[ti], d, h, n, dpdu)) continue;
-                best_t = h.t;
-                best_prim = ti;
-                best_b1 = h.b1;
-                best_b2 = h.b2;
-            }
-        } else {
-            uint32_t axis = node.b & 3u;
-            uint32_t left = ni + 1, right = node.a;
-            if (comp(d, (int)axis) > 0.0f) {
-                stk.put(sp++, right);
-                stk.put(sp++, left);
-            } else {
-                stk.put(sp++, left);
-                stk.put(sp++, right);
-            }
-        }
-        ray_t_max = best_t;  // blas.rs:468 (not reached on a bbox miss)
-    }
-    if (best_t < pn_inf()) {
-        out_t = best_t;
-        out_prim = best_prim;
-        out_b1 = best_b1;
-        out_b2 = best_b2;
-        return true;
-    }
-    return false;
-}
-
-// intersect_bvh_pred (blas.rs:478-495): a pure OR over leaves reached through intersecting boxes, so
-// visiting order is free; depth-first with the same LDS stack.
-template <bool STATS>
-PD bool blas_any(const DevScene& S, const pbrs_mesh& mesh, f3 o, f3 d, float t_max, LaneStack stk, int sp, Cnt<STATS>& cnt) {
-    const int base = sp;
-    stk.put(sp++, mesh.root);
-    while (sp > base) {
-        uint32_t ni = stk.get(--sp);
-        pbrs_node node = load_node(S.blas + ni);
-        CNT(blas_nodes);
-        if (!slab_test(nmin(node), nmax(node), o, d, t_max)) continue;
-        if (node.b & PBRS_LEAF_FLAG) {
-            uint32_t count = node.b & ~PBRS_LEAF_FLAG;
-            for (uint32_t k = 0; k < count; ++k) {
-                pbrs_tri_verts tv = load_tri(S.tv + node.a + k);
-                CNT(triangles);
-                if (tri_pred(ld3(tv.p0), ld3(tv.p1), ld3(tv.p2), o, d, t_max)) return true;
-            }
-        } else {
-            stk.put(sp++, node.a);
-            stk.put(sp++, ni + 1);
-        }
-    }
-    return false;
-}
-
-// BvhNode::intersect (tlas/src/bvh.rs:77-103) + Instance::intersect (tlas/src/instance.rs:50-67, ray
-// transform and `t` only).  The recursion visits left then right with ray.t_max lowered to the left
-// result; iteratively: pop, test the box against the current t_max, push right then left.
-// Candidate replaces the best when !(best.t < cand.t), the rule of bvh.rs:94-98.
-// Known deviation: the reference can RAISE ray.t_max after a mesh instance
-// returns a hit beyond it (blas.rs:468 drops the incoming extent); here t_max is always the best t so
-// far.  The two differ only if two instances hit at bit-identical t (oracle counter `tlas_ties`).
-template <bool STATS>
-PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
-    best.t = pn_inf();
-    best.inst = 0xffffffffu;
-    best.prim = 0;
-    best.b1 = best.b2 = 0.0f;
-    bool have = false;
-    int sp = 0;
-    stk.put(sp++, 0u);
-    while (sp > 0) {
-        uint32_t ni = stk.get(--sp);
-        pbrs_node node = load_node(S.tlas + ni);
-        CNT(tlas_nodes);
-        if (!slab_test(nmin(node), nmax(node), o, d, t_max)) continue;
-        if (!(node.b & PBRS_LEAF_FLAG)) {
-            stk.put(sp++, node.a);
-            stk.put(sp++, ni + 1);
-            continue;
-        }
-        const pbrs_instance& in = S.inst[node.a];
-        CNT(instances);
-        f3 oo = xf_apply(in.inv, o, 1.0f);
-        f3 od = xf_apply(in.inv, d, 0.0f);
-        float t = 0.0f, b1 = 0.0f, b2 = 0.0f;
-        uint32_t prim = 0;
-        bool hit = false;
-        switch (in.shape_kind) {
-            case PBRS_SHAPE_SPHERE: {
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(spheres);
-                hit = sphere_hit_t(ld3(p), p[3], oo, od, t_max, t);
-                break;
-            }
-            case PBRS_SHAPE_QUAD: {
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(quads);
-                float u, v;
-                f3 n;
-                hit = quad_hit(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, t, u, v, n);
-                break;
-            }
-            case PBRS_SHAPE_CUBOID: {
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(cuboids);
-                int axis;
-                float bound;
-                hit = cuboid_hit(ld3(p), ld3(p + 3), oo, od, t_max, t, axis, bound);
-                break;
-            }
-            case PBRS_SHAPE_DISK: {
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(disks);
-                hit = disk_hit_t(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, t);
-                break;
-            }
-            case PBRS_SHAPE_TRIANGLE: {
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(triangles);
-                TriHit h;
-                hit = tri_hit(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, h);
-                if (hit) {
-                    t = h.t;
-                    b1 = h.b1;
-                    b2 = h.b2;
-                }
-                break;
-            }
-            default: {
-                pbrs_mesh mesh = S.meshes[in.shape_index];
-                hit = blas_closest<STATS>(S, mesh, oo, od, t_max, stk, sp, t, prim, b1, b2, cnt);
-                break;
-            }
-        }
-        if (!hit) continue;
-        CNT(instance_hits);
-        if (!have || !(best.t < t)) {
-            have = true;
-            best.t = t;
-            best.inst = node.a;
-            best.prim = prim;
-            best.b1 = b1;
-            best.b2 = b2;
-            t_max = t;  // ray.set_extent (bvh.rs:85-87); never raised — see the deviation note above
-        }
-    }
-}
-
-// BvhNode::occludes (bvh.rs:105-113) + Instance::occludes (instance.rs:68-72).
-template <bool STATS>
-PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
-    int sp = 0;
-    stk.put(sp++, 0u);
-    while (sp > 0) {
-        uint32_t ni = stk.get(--sp);
-        pbrs_node node = load_node(S.tlas + ni);
-        CNT(tlas_nodes);
-        if (!slab_test(nmin(node), nmax(node), o, d, t_max)) continue;
-        if (!(node.b & PBRS_LEAF_FLAG)) {
-            stk.put(sp++, node.a);
-            stk.put(sp++, ni + 1);
-            continue;
-        }
-        const pbrs_instance& in = S.inst[node.a];
-        CNT(instances);
-        f3 oo = xf_apply(in.inv, o, 1.0f);
-        f3 od = xf_apply(in.inv, d, 0.0f);
-        bool occ = false;
-        switch (in.shape_kind) {
-            case PBRS_SHAPE_SPHERE: {
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(spheres);
-                occ = sphere_occludes(ld3(p), p[3], oo, od, t_max);
-                break;
-            }
-            case PBRS_SHAPE_QUAD: {
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(quads);
-                occ = quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
-                break;
-            }
-            case PBRS_SHAPE_CUBOID: {  // Q14: the bbox slab test
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(cuboids);
-                occ = slab_test(ld3(p), ld3(p + 3), oo, od, t_max);
-                break;
-            }
-            case PBRS_SHAPE_DISK: {
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(disks);
-                occ = disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od);
-                break;
-            }
-            case PBRS_SHAPE_TRIANGLE: {
-                const float* p = S.shapes[in.shape_index].p;
-                CNT(triangles);
-                occ = tri_pred(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
-                break;
-            }
-            default: {
-                pbrs_mesh mesh = S.meshes[in.shape_index];
-                occ = blas_any<STATS>(S, mesh, oo, od, t_max, stk, sp, cnt);
-                break;
-            }
-        }
-        if (occ) return true;
-    }
-    return false;
-}
 
 // Rebuilds the reference's world-space Interaction for the winning primitive: the object-space
 // Interaction of the shape, then AffineTransform::apply (geometry/src/transform.rs:309-320).

@@ -1,0 +1,315 @@
+// device/traverse.h — two-level BVH traversal for `extend` (closest hit) and `shadow` (any hit).
+//
+// Restates tlas/src/bvh.rs:77-113 (BvhNode::intersect / occludes), tlas/src/instance.rs:50-72 and
+// shape/src/blas.rs:422-495 (intersect_bvh / intersect_bvh_pred) for one lane = one ray.
+//
+// MI355X shape of the loop.  The reference recurses through the TLAS and runs a second, nested loop
+// per mesh instance.  On a 64-wide wave a nested loop makes every lane wait while a few lanes walk a
+// BLAS, so TLAS and BLAS share ONE pending-node stack (per lane, in LDS, lane-major) and ONE
+// "while-while" loop (Aila & Laine style): the inner loop pops nodes of whichever tree the lane is in
+// and only runs the box test; a lane leaves it when it holds a leaf, the wave reconverges, and all
+// lanes holding a leaf run the (expensive, divergent) leaf work together: triangle tests for a
+// BLAS leaf, the instance transform + analytic shape test (or BLAS entry) for a TLAS leaf.
+//
+// Box test.  geometry/src/bvh.rs:84-99 divides six times per node; IEEE f32 division costs ~11
+// instructions on gfx950.  `(float)((double)n * R)` with R = rn64(1/(double)d) IS the correctly rounded
+// f32 quotient whenever no f32 overflow/underflow is involved: the f64 product is within 2^-52 of n/d,
+// while n/d (a ratio of two 24-bit significands) is either exactly an f32 or at least 2^-49 (relative)
+// away from every f32 rounding boundary, so the two round to the same f32.  R is computed once per ray
+// and per instance; each quotient is then cvt + v_mul_f64 + cvt.  Lanes whose ray leaves the guarded
+// range (a zero / denormal / huge direction component, an origin component that is tiny but non-zero)
+// take the reference's literal divisions instead; pbrs_upload_scene checks the node coordinates once.
+#pragma once
+#include "shapes.h"
+
+struct RaySpace {
+    f3 o, d;
+    double rx, ry, rz;  // rn64(1 / d)
+    bool fast;
+};
+PD bool dir_in_range(float x) {  // normal, 2^-40 <= |x| <= 2^40
+    uint32_t e = (pn_bits(x) >> 23) & 0xffu;
+    return e >= 127u - 40u && e <= 127u + 40u;
+}
+PD bool origin_in_range(float x) {  // zero, or 2^-60 <= |x| <= 2^40
+    uint32_t u = pn_bits(x) & 0x7fffffffu;
+    uint32_t e = u >> 23;
+    return u == 0u || (e >= 127u - 60u && e <= 127u + 40u);
+}
+PD RaySpace make_space(f3 o, f3 d, bool scene_ok) {
+    RaySpace r;
+    r.o = o;
+    r.d = d;
+    r.fast = scene_ok && dir_in_range(d.x) && dir_in_range(d.y) && dir_in_range(d.z) && origin_in_range(o.x) && origin_in_range(o.y) &&
+             origin_in_range(o.z);
+    r.rx = r.ry = r.rz = 0.0;
+    if (r.fast) {
+        r.rx = 1.0 / (double)d.x;
+        r.ry = 1.0 / (double)d.y;
+        r.rz = 1.0 / (double)d.z;
+    }
+    return r;
+}
+PD float qdiv(float n, double r) { return (float)((double)n * r); }
+// geometry/src/bvh.rs:84-99 (same min/max/NaN conventions as dmath.h::slab_test)
+PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
+    if (!R.fast) return slab_test(nmin(n), nmax(n), R.o, R.d, t_max);
+    float t0x = qdiv(n.min[0] - R.o.x, R.rx), t0y = qdiv(n.min[1] - R.o.y, R.ry), t0z = qdiv(n.min[2] - R.o.z, R.rz);
+    float t1x = qdiv(n.max[0] - R.o.x, R.rx), t1y = qdiv(n.max[1] - R.o.y, R.ry), t1z = qdiv(n.max[2] - R.o.z, R.rz);
+    float lox = sse_min(t0x, t1x), loy = sse_min(t0y, t1y), loz = sse_min(t0z, t1z);
+    float hix = sse_max(t0x, t1x), hiy = sse_max(t0y, t1y), hiz = sse_max(t0z, t1z);
+    float lo_el = sse_max(sse_max(lox, loz), sse_max(loy, loz));
+    float hi_el = sse_min(sse_min(hix, hiz), sse_min(hiy, hiz));
+    float t_low = pn_max(lo_el, 0.0f);
+    float t_high = pn_min(hi_el, t_max);
+    return t_low <= t_high;
+}
+
+// Closest hit.  Semantics kept from the reference:
+//  * TLAS: left subtree, then right, ray.t_max lowered to the left result (bvh.rs:84-88) == pop order
+//    i+1 before a, box test at pop time against the current t_max.
+//  * a candidate replaces the best when !(best.t < cand.t) (bvh.rs:94-98).
+//  * BLAS: root tested against the incoming extent, every later node against the mesh-local best
+//    only (`ray.t_max = outer_hit.ray_t`, blas.rs:468, runs after a node passed its box test);
+//    children pushed far-then-near by `ray.dir[axis] > 0` (blas.rs:456-466); within a leaf the
+//    triangles see the t_max from before the leaf and `new.t < outer.t` keeps the first of equals.
+//  * the mesh may return a hit beyond the incoming extent (it loses at the TLAS compare).
+// Known deviation: ray.t_max is never RAISED by such an overshoot; observable only on
+// bit-identical t from two instances (oracle counter tlas_ties).
+template <bool STATS>
+PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
+    best.t = pn_inf();
+    best.inst = 0xffffffffu;
+    best.prim = 0;
+    best.b1 = best.b2 = 0.0f;
+    bool have = false;
+    const RaySpace W = make_space(o, d, S.fast_slab != 0);
+    RaySpace B = W;
+    bool in_blas = false;
+    int sp = 0, blas_base = 0;
+    uint32_t cur_inst = 0;
+    float lt = 0.0f;          // the cloned ray's t_max inside intersect_bvh
+    float mt = pn_inf();      // outer_hit.ray_t
+    uint32_t mprim = 0;
+    float mb1 = 0.0f, mb2 = 0.0f;
+    stk.put(sp++, 0u);
+    for (;;) {
+        bool leaf = false;
+        pbrs_node node;
+        uint32_t ni = 0;
+        while (!leaf) {
+            if (in_blas && sp == blas_base) {  // intersect_bvh returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
+                in_blas = false;
+                if (mt < pn_inf()) {
+                    CNT(instance_hits);
+                    if (!have || !(best.t < mt)) {
+                        have = true;
+                        best.t = mt;
+                        best.inst = cur_inst;
+                        best.prim = mprim;
+                        best.b1 = mb1;
+                        best.b2 = mb2;
+                        t_max = mt;
+                    }
+                }
+            }
+            if (sp == 0) break;
+            ni = stk.get(--sp);
+            node = load_node((in_blas ? S.blas : S.tlas) + ni);
+            bool pass;
+            if (in_blas) {
+                CNT(blas_nodes);
+                pass = slab_rs(node, B, lt);
+            } else {
+                CNT(tlas_nodes);
+                pass = slab_rs(node, W, t_max);
+            }
+            if (!pass) continue;
+            if (node.b & PBRS_LEAF_FLAG) {
+                leaf = true;
+            } else if (in_blas) {
+                uint32_t axis = node.b & 3u;
+                uint32_t left = ni + 1, right = node.a;
+                bool left_first = comp(B.d, (int)axis) > 0.0f;
+                stk.put(sp++, left_first ? right : left);
+                stk.put(sp++, left_first ? left : right);
+                lt = mt;
+            } else {
+                stk.put(sp++, node.a);
+                stk.put(sp++, ni + 1);
+            }
+        }
+        if (!leaf) break;
+        if (in_blas) {
+            uint32_t count = node.b & ~PBRS_LEAF_FLAG;
+            for (uint32_t k = 0; k < count; ++k) {
+                uint32_t ti = node.a + k;
+                pbrs_tri_verts tv = load_tri(S.tv + ti);
+                CNT(triangles);
+                TriHit h;
+                if (!tri_hit(ld3(tv.p0), ld3(tv.p1), ld3(tv.p2), B.o, B.d, lt, h)) continue;
+                CNT(tri_shading);
+                // The reference builds the shading frame of every geometric hit (blas.rs:166-206); only a hit
+                // that would replace outer_hit can change the result, so only those pay for it.
+                if (!(h.t < mt)) continue;
+                f3 n, dpdu;
+                if (!mesh_tri_shading(tv, S.ts[ti], B.d, h, n, dpdu)) continue;
+                mt = h.t;
+                mprim = ti;
+                mb1 = h.b1;
+                mb2 = h.b2;
+            }
+            lt = mt;
+            continue;
+        }
+        // TLAS leaf: Instance::intersect (instance.rs:50-67)
+        const pbrs_instance& in = S.inst[node.a];
+        CNT(instances);
+        f3 oo = xf_apply(in.inv, o, 1.0f);
+        f3 od = xf_apply(in.inv, d, 0.0f);
+        if (in.shape_kind == PBRS_SHAPE_MESH) {
+            B = make_space(oo, od, S.fast_slab != 0);
+            in_blas = true;
+            blas_base = sp;
+            cur_inst = node.a;
+            lt = t_max;
+            mt = pn_inf();
+            stk.put(sp++, S.meshes[in.shape_index].root);
+            continue;
+        }
+        const float* p = S.shapes[in.shape_index].p;
+        float t = 0.0f, b1 = 0.0f, b2 = 0.0f;
+        bool hit = false;
+        switch (in.shape_kind) {
+            case PBRS_SHAPE_SPHERE:
+                CNT(spheres);
+                hit = sphere_hit_t(ld3(p), p[3], oo, od, t_max, t);
+                break;
+            case PBRS_SHAPE_QUAD: {
+                CNT(quads);
+                float u, v;
+                f3 n;
+                hit = quad_hit(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, t, u, v, n);
+                break;
+            }
+            case PBRS_SHAPE_CUBOID: {
+                CNT(cuboids);
+                int axis;
+                float bound;
+                hit = cuboid_hit(ld3(p), ld3(p + 3), oo, od, t_max, t, axis, bound);
+                break;
+            }
+            case PBRS_SHAPE_DISK:
+                CNT(disks);
+                hit = disk_hit_t(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, t);
+                break;
+            default: {  // PBRS_SHAPE_TRIANGLE
+                CNT(triangles);
+                TriHit h;
+                hit = tri_hit(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, h);
+                if (hit) {
+                    t = h.t;
+                    b1 = h.b1;
+                    b2 = h.b2;
+                }
+                break;
+            }
+        }
+        if (!hit) continue;
+        CNT(instance_hits);
+        if (!have || !(best.t < t)) {
+            have = true;
+            best.t = t;
+            best.inst = node.a;
+            best.prim = 0;
+            best.b1 = b1;
+            best.b2 = b2;
+            t_max = t;
+        }
+    }
+}
+
+// Any hit: BvhNode::occludes (bvh.rs:105-113), Instance::occludes (instance.rs:68-72), intersect_bvh_pred
+// (blas.rs:478-495).  A pure OR over the leaves reached through intersecting boxes with a fixed extent, so
+// the visiting order is free and nothing is carried between instances: same single loop, no best-hit state.
+// Order kept left-first anyway so the work counters equal the reference's short-circuit evaluation.
+template <bool STATS>
+PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
+    const RaySpace W = make_space(o, d, S.fast_slab != 0);
+    RaySpace B = W;
+    bool in_blas = false;
+    int sp = 0, blas_base = 0;
+    stk.put(sp++, 0u);
+    for (;;) {
+        bool leaf = false;
+        pbrs_node node;
+        uint32_t ni = 0;
+        while (!leaf) {
+            if (in_blas && sp == blas_base) in_blas = false;
+            if (sp == 0) break;
+            ni = stk.get(--sp);
+            node = load_node((in_blas ? S.blas : S.tlas) + ni);
+            bool pass;
+            if (in_blas) {
+                CNT(blas_nodes);
+                pass = slab_rs(node, B, t_max);
+            } else {
+                CNT(tlas_nodes);
+                pass = slab_rs(node, W, t_max);
+            }
+            if (!pass) continue;
+            if (node.b & PBRS_LEAF_FLAG) {
+                leaf = true;
+            } else {
+                stk.put(sp++, node.a);
+                stk.put(sp++, ni + 1);
+            }
+        }
+        if (!leaf) return false;
+        if (in_blas) {
+            uint32_t count = node.b & ~PBRS_LEAF_FLAG;
+            for (uint32_t k = 0; k < count; ++k) {
+                pbrs_tri_verts tv = load_tri(S.tv + node.a + k);
+                CNT(triangles);
+                if (tri_pred(ld3(tv.p0), ld3(tv.p1), ld3(tv.p2), B.o, B.d, t_max)) return true;
+            }
+            continue;
+        }
+        const pbrs_instance& in = S.inst[node.a];
+        CNT(instances);
+        f3 oo = xf_apply(in.inv, o, 1.0f);
+        f3 od = xf_apply(in.inv, d, 0.0f);
+        if (in.shape_kind == PBRS_SHAPE_MESH) {
+            B = make_space(oo, od, S.fast_slab != 0);
+            in_blas = true;
+            blas_base = sp;
+            stk.put(sp++, S.meshes[in.shape_index].root);
+            continue;
+        }
+        const float* p = S.shapes[in.shape_index].p;
+        bool occ = false;
+        switch (in.shape_kind) {
+            case PBRS_SHAPE_SPHERE:
+                CNT(spheres);
+                occ = sphere_occludes(ld3(p), p[3], oo, od, t_max);
+                break;
+            case PBRS_SHAPE_QUAD:
+                CNT(quads);
+                occ = quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
+                break;
+            case PBRS_SHAPE_CUBOID:  // Q14: the bbox slab test
+                CNT(cuboids);
+                occ = slab_test(ld3(p), ld3(p + 3), oo, od, t_max);
+                break;
+            case PBRS_SHAPE_DISK:
+                CNT(disks);
+                occ = disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od);
+                break;
+            default:
+                CNT(triangles);
+                occ = tri_pred(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
+                break;
+        }
+        if (occ) return true;
+    }
+}

@@ -442,6 +442,20 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     std::memcpy(S.env, d->env_constant, sizeof S.env);
     // Scene::has_env_light for EnvLight::Constant (scene/src/lib.rs:96-102): !c.is_black()
     S.has_env = !(S.env[0] <= 0.0f && S.env[1] <= 0.0f && S.env[2] <= 0.0f) ? 1u : 0u;
+    // The f64-reciprocal box test (device/traverse.h) is exact when every node coordinate b is finite,
+    // |b| <= 2^40 and (b == 0 or |b| >= 2^-20); otherwise every lane uses the literal divisions.
+    {
+        auto coord_ok = [](float b) {
+            uint32_t u = pn_bits(b) & 0x7fffffffu, e = u >> 23;
+            return u == 0u || (e >= 127u - 20u && e <= 127u + 40u);
+        };
+        bool ok = true;
+        for (uint32_t i = 0; i < d->n_tlas_nodes && ok; ++i)
+            for (int a = 0; a < 3; ++a) ok = ok && coord_ok(d->tlas_nodes[i].min[a]) && coord_ok(d->tlas_nodes[i].max[a]);
+        for (uint32_t i = 0; i < d->n_blas_nodes && ok; ++i)
+            for (int a = 0; a < 3; ++a) ok = ok && coord_ok(d->blas_nodes[i].min[a]) && coord_ok(d->blas_nodes[i].max[a]);
+        S.fast_slab = ok ? 1u : 0u;
+    }
     c->S = S;
     c->stack_depth = depth;
     c->has_scene = true;
