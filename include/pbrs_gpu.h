@@ -39,6 +39,7 @@ extern "C" {
 #define PBRS_E_LIMIT (-4)     /* traversal stack deeper than the LDS budget, tile too large, ... */
 
 #define PBRS_LEAF_FLAG 0x80000000u
+#define PBRS_TLAS_LEAF_KIND_SHIFT 8 /* TLAS leaves also carry the instance's shape kind in bits 8..10 of b */
 
 /* A BVH node, 32 B, pre-order: the left child of node i is node i+1.
  *   inner: a = index of the right child, b = split axis (BLAS; 0 for TLAS)
@@ -59,8 +60,15 @@ typedef struct pbrs_instance {
     uint32_t shape_kind;  /* enum pbrs_shape_kind (pbrs_scene_spec.h) */
     uint32_t shape_index; /* analytic: index into shapes[]; mesh: index into meshes[] */
     uint32_t material;
-    uint32_t pad;
+    uint32_t flags; /* PBRS_INSTANCE_* */
+    /* mesh instances: copies of meshes[shape_index].root / .flags so that entering the BLAS costs one record */
+    uint32_t blas_root;
+    uint32_t mesh_flags;
+    uint32_t pad[2];
 } pbrs_instance;
+/* inv and fwd are bit-exactly the identity: for a ray whose components are all finite and non-zero
+ * `inverse * ray` (tlas/src/instance.rs:51) returns the ray's own bits, so the product can be skipped. */
+#define PBRS_INSTANCE_IDENTITY 1u
 
 /* Analytic shape parameters, 12 floats (shape/src/simple.rs:10-196), laid out as in pbrs_shape_spec.p;
  * cuboid min/max already ordered (Cuboid::from_points), disk normal already unit (Disk::new). */
@@ -74,25 +82,32 @@ typedef struct pbrs_mesh {
     uint32_t first_tri;  /* first triangle of this mesh in tri_verts[] / tri_shade[] */
     uint32_t n_tris;
     uint32_t height;     /* IsoBvhNode::height(), shape/src/blas.rs:21-26 */
-    uint32_t pad[3];
+    uint32_t flags;      /* PBRS_MESH_* */
+    uint32_t pad[2];
 } pbrs_mesh;
+/* Every triangle of the mesh has three bit-identical vertex normals AND passes the tangent check of
+ * shape/src/blas.rs:193-200 (which then depends on the triangle only, not on the hit or the ray), so the
+ * traversal need not evaluate the shading frame of candidate hits. */
+#define PBRS_MESH_FLAT_SHADING_OK 1u
 
 /* One triangle's geometry in BLAS leaf order, Q11 swap applied: `let (i,k,j) = index_triple`
- * (shape/src/blas.rs:162) => p0 = positions[i], p1 = positions[j], p2 = positions[k]. */
+ * (shape/src/blas.rs:162) => p0 = positions[i], p1 = positions[j], p2 = positions[k].
+ * n = `(p0 - p1).cross(p2 - p1).try_hat()` (shape/src/simple.rs:436), which depends on the triangle only:
+ * evaluated once by the host with the reference's operand order; all-NaN when try_hat returns None. */
 typedef struct pbrs_tri_verts {
     float p0[3];
-    uint32_t orig; /* index of the triangle in the input index buffer */
+    float nx;
     float p1[3];
-    float pad1;
+    float ny;
     float p2[3];
-    float pad2;
+    float nz;
 } pbrs_tri_verts;
 
 /* Shading attributes of the same triangle, same vertex order (shape/src/blas.rs:170-185). */
 typedef struct pbrs_tri_shade {
     float n0[3], n1[3], n2[3];
     float uv0[2], uv1[2], uv2[2];
-    float pad;
+    uint32_t orig; /* index of the triangle in the input index buffer */
 } pbrs_tri_shade;
 
 /* geometry/src/bxdf.rs:263-269 flattened (textures are Solid, so `bxdfs_at` is constant per material). */

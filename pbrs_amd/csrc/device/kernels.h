@@ -135,6 +135,14 @@ __global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const 
         st.hb1[slot] = h.b1;
         st.hb2[slot] = h.b2;
     }
+#ifdef PBRS_TAIL_PROBE  // developer probe: wave-level max vs sum of per-lane node counts (tail divergence)
+    if (STATS) {
+        uint32_t mine = valid ? cnt.c.tlas_nodes + cnt.c.blas_nodes : 0u, mx = mine;
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
+        cnt.c.quads = (threadIdx.x & 63u) == 0 ? mx * 64u : 0u;
+        cnt.c.disks = mine;
+    }
+#endif
     flush_counters<STATS>(cnt, gc, valid, 1u, nhit);
 }
 
@@ -387,7 +395,7 @@ __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, 
         r.t = h.t;
         r.inst = h.inst;
         r.prim = 0;
-        if (h.inst != 0xffffffffu && S.inst[h.inst].shape_kind == PBRS_SHAPE_MESH) r.prim = S.tv[h.prim].orig;
+        if (h.inst != 0xffffffffu && S.inst[h.inst].shape_kind == PBRS_SHAPE_MESH) r.prim = S.ts[h.prim].orig;
         r.b1 = h.b1;
         r.b2 = h.b2;
         hits[i] = r;

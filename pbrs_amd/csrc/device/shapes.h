@@ -312,10 +312,51 @@ PD pbrs_tri_verts load_tri(const pbrs_tri_verts* p) {
     const float4* q = reinterpret_cast<const float4*>(p);
     float4 a = q[0], b = q[1], c = q[2];
     pbrs_tri_verts t;
-    t.p0[0] = a.x; t.p0[1] = a.y; t.p0[2] = a.z; t.orig = __float_as_uint(a.w);
-    t.p1[0] = b.x; t.p1[1] = b.y; t.p1[2] = b.z; t.pad1 = 0.0f;
-    t.p2[0] = c.x; t.p2[1] = c.y; t.p2[2] = c.z; t.pad2 = 0.0f;
+    t.p0[0] = a.x; t.p0[1] = a.y; t.p0[2] = a.z; t.nx = a.w;
+    t.p1[0] = b.x; t.p1[1] = b.y; t.p1[2] = b.z; t.ny = b.w;
+    t.p2[0] = c.x; t.p2[1] = c.y; t.p2[2] = c.z; t.nz = c.w;
     return t;
+}
+// intersect_triangle / intersect_triangle_pred (simple.rs:435-495) with `(p0-p1).cross(p2-p1).try_hat()`
+// taken from the flattened triangle (host-evaluated with the same operand order; NaN = try_hat was None).
+PD bool mesh_tri_hit(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max, TriHit& h) {
+    if (tv.nx != tv.nx) return false;
+    f3 p0 = ld3(tv.p0), p1 = ld3(tv.p1), p2 = ld3(tv.p2);
+    f3 normal = facing(mk3(tv.nx, tv.ny, tv.nz), d);
+    float t = dot(normal, p0 - o) / dot(normal, d);
+    if (!truncated_t(t, t_max)) return false;
+    f3 p = o + t * d;
+    float b2 = dot(cross(p - p0, p - p1), normal);
+    float b0 = dot(cross(p - p1, p - p2), normal);
+    float b1 = dot(cross(p - p2, p - p0), normal);
+    if (pn_isnan(b0) || pn_isnan(b1) || pn_isnan(b2)) return false;
+    bool s0 = b0 > 0.0f, s1 = b1 > 0.0f, s2 = b2 > 0.0f;
+    if (!((s0 && s1 && s2) || (!s0 && !s1 && !s2))) return false;
+    float total_area = b0 + b1 + b2;
+    b0 = b0 / total_area;
+    b1 = b1 / total_area;
+    b2 = b2 / total_area;
+    f3 hit_pos = bary_lerp(p0, p1, p2, b0, b1);
+    if (has_nan3(hit_pos)) return false;
+    h.t = t;
+    h.b0 = b0;
+    h.b1 = b1;
+    h.b2 = b2;
+    h.normal = normal;
+    return true;
+}
+PD bool mesh_tri_pred(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max) {
+    if (tv.nx != tv.nx) return false;
+    f3 p0 = ld3(tv.p0), p1 = ld3(tv.p1), p2 = ld3(tv.p2);
+    f3 normal = mk3(tv.nx, tv.ny, tv.nz);
+    float t = dot(normal, p0 - o) / dot(normal, d);
+    if (!truncated_t(t, t_max)) return false;
+    f3 p = o + t * d;
+    float b0 = dot(cross(p - p0, p - p1), normal);
+    float b1 = dot(cross(p - p1, p - p2), normal);
+    float b2 = dot(cross(p - p2, p - p0), normal);
+    bool s0 = b0 > 0.0f, s1 = b1 > 0.0f, s2 = b2 > 0.0f;
+    return (s0 && s1 && s2) || (!s0 && !s1 && !s2);
 }
 
 // A per-lane stack in LDS: entry `level` of lane `lane` at stk[level * stride + lane].
@@ -369,7 +410,7 @@ PD Isect reconstruct_isect(const DevScene& S, const Hit& h, f3 o, f3 d) {
             pbrs_tri_verts tv = load_tri(S.tv + h.prim);
             f3 p0 = ld3(tv.p0), p1 = ld3(tv.p1), p2 = ld3(tv.p2);
             TriHit th;
-            tri_hit(p0, p1, p2, oo, od, pn_inf(), th);
+            mesh_tri_hit(tv, oo, od, pn_inf(), th);
             f3 n, dpdu;
             mesh_tri_shading(tv, S.ts[h.prim], od, th, n, dpdu);
             li.pos = bary_lerp(p0, p1, p2, th.b0, th.b1);

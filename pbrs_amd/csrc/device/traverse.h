@@ -6,10 +6,10 @@
 // MI355X shape of the loop.  The reference recurses through the TLAS and runs a second, nested loop
 // per mesh instance.  On a 64-wide wave a nested loop makes every lane wait while a few lanes walk a
 // BLAS, so TLAS and BLAS share ONE pending-node stack (per lane, in LDS, lane-major) and ONE
-// "while-while" loop (Aila & Laine style): the inner loop pops nodes of whichever tree the lane is in
-// and only runs the box test; a lane leaves it when it holds a leaf, the wave reconverges, and all
-// lanes holding a leaf run the (expensive, divergent) leaf work together: triangle tests for a
-// BLAS leaf, the instance transform + analytic shape test (or BLAS entry) for a TLAS leaf.
+// "while-while" loop: the inner loop pops nodes of whichever tree the lane is in, runs the box test
+// and enters mesh instances inline (a ray transform, or nothing for an identity instance); a lane
+// leaves it only when it holds primitives to test (a BLAS leaf or an analytic shape), the wave
+// reconverges, and all lanes holding primitives run the expensive, divergent part together.
 //
 // Box test.  geometry/src/bvh.rs:84-99 divides six times per node; IEEE f32 division costs ~11
 // instructions on gfx950.  `(float)((double)n * R)` with R = rn64(1/(double)d) IS the correctly rounded
@@ -65,6 +65,17 @@ PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
     return t_low <= t_high;
 }
 
+// `self.transform.inverse().apply(*ray)` (tlas/src/instance.rs:51).  For an instance whose matrices are
+// bit-exactly the identity the Mat4 products return the operand's own bits as long as every component
+// is finite and non-zero (1*x + 0*y + 0*z + 0*w = x exactly), which is what W.fast plus a non-zero
+// origin guarantee; anything else takes the literal products.
+PD RaySpace enter_instance(const DevScene& S, const pbrs_instance& in, const RaySpace& W) {
+    if ((in.flags & PBRS_INSTANCE_IDENTITY) && W.fast && W.o.x != 0.0f && W.o.y != 0.0f && W.o.z != 0.0f) return W;
+    f3 oo = xf_apply(in.inv, W.o, 1.0f);
+    f3 od = xf_apply(in.inv, W.d, 0.0f);
+    return make_space(oo, od, S.fast_slab != 0);
+}
+
 // Closest hit.  Semantics kept from the reference:
 //  * TLAS: left subtree, then right, ray.t_max lowered to the left result (bvh.rs:84-88) == pop order
 //    i+1 before a, box test at pop time against the current t_max.
@@ -87,9 +98,9 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
     RaySpace B = W;
     bool in_blas = false;
     int sp = 0, blas_base = 0;
-    uint32_t cur_inst = 0;
-    float lt = 0.0f;          // the cloned ray's t_max inside intersect_bvh
-    float mt = pn_inf();      // outer_hit.ray_t
+    uint32_t cur_inst = 0, mesh_flags = 0;
+    float lt = 0.0f;      // the cloned ray's t_max inside intersect_bvh
+    float mt = pn_inf();  // outer_hit.ray_t
     uint32_t mprim = 0;
     float mb1 = 0.0f, mb2 = 0.0f;
     stk.put(sp++, 0u);
@@ -125,18 +136,34 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
                 pass = slab_rs(node, W, t_max);
             }
             if (!pass) continue;
-            if (node.b & PBRS_LEAF_FLAG) {
-                leaf = true;
-            } else if (in_blas) {
-                uint32_t axis = node.b & 3u;
-                uint32_t left = ni + 1, right = node.a;
-                bool left_first = comp(B.d, (int)axis) > 0.0f;
-                stk.put(sp++, left_first ? right : left);
-                stk.put(sp++, left_first ? left : right);
-                lt = mt;
-            } else {
+            if (in_blas) {
+                if (node.b & PBRS_LEAF_FLAG) {
+                    leaf = true;
+                } else {
+                    uint32_t axis = node.b & 3u;
+                    uint32_t left = ni + 1, right = node.a;
+                    bool left_first = comp(B.d, (int)axis) > 0.0f;
+                    stk.put(sp++, left_first ? right : left);
+                    stk.put(sp++, left_first ? left : right);
+                    lt = mt;
+                }
+            } else if (!(node.b & PBRS_LEAF_FLAG)) {
                 stk.put(sp++, node.a);
                 stk.put(sp++, ni + 1);
+            } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
+                // Instance::intersect of a mesh (instance.rs:50-53): enter its BLAS without leaving the node loop
+                const pbrs_instance& in = S.inst[node.a];
+                CNT(instances);
+                B = enter_instance(S, in, W);
+                in_blas = true;
+                blas_base = sp;
+                cur_inst = node.a;
+                mesh_flags = in.mesh_flags;
+                lt = t_max;
+                mt = pn_inf();
+                stk.put(sp++, in.blas_root);
+            } else {
+                leaf = true;
             }
         }
         if (!leaf) break;
@@ -147,13 +174,16 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
                 pbrs_tri_verts tv = load_tri(S.tv + ti);
                 CNT(triangles);
                 TriHit h;
-                if (!tri_hit(ld3(tv.p0), ld3(tv.p1), ld3(tv.p2), B.o, B.d, lt, h)) continue;
+                if (!mesh_tri_hit(tv, B.o, B.d, lt, h)) continue;
                 CNT(tri_shading);
-                // The reference builds the shading frame of every geometric hit (blas.rs:166-206); only a hit
-                // that would replace outer_hit can change the result, so only those pay for it.
+                // The reference builds the shading frame of every geometric hit (blas.rs:166-206) and drops the
+                // hit when the tangent check fails (Q22).  Only a hit that would replace outer_hit can change the
+                // result, and for a flat-shaded mesh the check is a host-verified property of the triangles.
                 if (!(h.t < mt)) continue;
-                f3 n, dpdu;
-                if (!mesh_tri_shading(tv, S.ts[ti], B.d, h, n, dpdu)) continue;
+                if (!(mesh_flags & PBRS_MESH_FLAT_SHADING_OK)) {
+                    f3 n, dpdu;
+                    if (!mesh_tri_shading(tv, S.ts[ti], B.d, h, n, dpdu)) continue;
+                }
                 mt = h.t;
                 mprim = ti;
                 mb1 = h.b1;
@@ -162,21 +192,11 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
             lt = mt;
             continue;
         }
-        // TLAS leaf: Instance::intersect (instance.rs:50-67)
+        // TLAS leaf holding an analytic shape: Instance::intersect (instance.rs:50-67)
         const pbrs_instance& in = S.inst[node.a];
         CNT(instances);
         f3 oo = xf_apply(in.inv, o, 1.0f);
         f3 od = xf_apply(in.inv, d, 0.0f);
-        if (in.shape_kind == PBRS_SHAPE_MESH) {
-            B = make_space(oo, od, S.fast_slab != 0);
-            in_blas = true;
-            blas_base = sp;
-            cur_inst = node.a;
-            lt = t_max;
-            mt = pn_inf();
-            stk.put(sp++, S.meshes[in.shape_index].root);
-            continue;
-        }
         const float* p = S.shapes[in.shape_index].p;
         float t = 0.0f, b1 = 0.0f, b2 = 0.0f;
         bool hit = false;
@@ -230,9 +250,10 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
 }
 
 // Any hit: BvhNode::occludes (bvh.rs:105-113), Instance::occludes (instance.rs:68-72), intersect_bvh_pred
-// (blas.rs:478-495).  A pure OR over the leaves reached through intersecting boxes with a fixed extent, so
-// the visiting order is free and nothing is carried between instances: same single loop, no best-hit state.
-// Order kept left-first anyway so the work counters equal the reference's short-circuit evaluation.
+// (blas.rs:478-495).  A pure OR over the leaves reached through intersecting boxes with a fixed extent:
+// the visiting order cannot change the answer and nothing is carried between instances, so BLAS children
+// are visited near-first (by the sign of the ray direction on the split axis), which reaches an occluder
+// sooner than the reference's left-first recursion.
 template <bool STATS>
 PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
     const RaySpace W = make_space(o, d, S.fast_slab != 0);
@@ -258,11 +279,28 @@ PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<
                 pass = slab_rs(node, W, t_max);
             }
             if (!pass) continue;
-            if (node.b & PBRS_LEAF_FLAG) {
-                leaf = true;
-            } else {
+            if (in_blas) {
+                if (node.b & PBRS_LEAF_FLAG) {
+                    leaf = true;
+                } else {
+                    uint32_t axis = node.b & 3u;
+                    uint32_t left = ni + 1, right = node.a;
+                    bool left_first = comp(B.d, (int)axis) > 0.0f;
+                    stk.put(sp++, left_first ? right : left);
+                    stk.put(sp++, left_first ? left : right);
+                }
+            } else if (!(node.b & PBRS_LEAF_FLAG)) {
                 stk.put(sp++, node.a);
                 stk.put(sp++, ni + 1);
+            } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
+                const pbrs_instance& in = S.inst[node.a];
+                CNT(instances);
+                B = enter_instance(S, in, W);
+                in_blas = true;
+                blas_base = sp;
+                stk.put(sp++, in.blas_root);
+            } else {
+                leaf = true;
             }
         }
         if (!leaf) return false;
@@ -271,7 +309,7 @@ PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<
             for (uint32_t k = 0; k < count; ++k) {
                 pbrs_tri_verts tv = load_tri(S.tv + node.a + k);
                 CNT(triangles);
-                if (tri_pred(ld3(tv.p0), ld3(tv.p1), ld3(tv.p2), B.o, B.d, t_max)) return true;
+                if (mesh_tri_pred(tv, B.o, B.d, t_max)) return true;
             }
             continue;
         }
@@ -279,13 +317,6 @@ PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<
         CNT(instances);
         f3 oo = xf_apply(in.inv, o, 1.0f);
         f3 od = xf_apply(in.inv, d, 0.0f);
-        if (in.shape_kind == PBRS_SHAPE_MESH) {
-            B = make_space(oo, od, S.fast_slab != 0);
-            in_blas = true;
-            blas_base = sp;
-            stk.put(sp++, S.meshes[in.shape_index].root);
-            continue;
-        }
         const float* p = S.shapes[in.shape_index].p;
         bool occ = false;
         switch (in.shape_kind) {

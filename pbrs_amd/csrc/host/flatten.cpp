@@ -224,6 +224,7 @@ Box shape_box(const pbrs_shape_spec& s, const std::vector<pbrs_mesh>& meshes, co
 // ---- TLAS (tlas/src/bvh.rs:116-152) -----------------------------------------------------------------------------
 struct TlasBuilder {
     const std::vector<Box>& inst_box;
+    const std::vector<pbrs_instance>& inst;
     std::vector<pbrs_node>& nodes;
     std::pair<uint32_t, uint32_t> build(std::vector<uint32_t> insts) {
         uint32_t idx = (uint32_t)nodes.size();
@@ -231,7 +232,7 @@ struct TlasBuilder {
         if (insts.size() == 1) {
             put_node(nodes[idx], inst_box[insts[0]]);  // BvhNode::new_leaf :44-49
             nodes[idx].a = insts[0];
-            nodes[idx].b = PBRS_LEAF_FLAG | 1u;
+            nodes[idx].b = PBRS_LEAF_FLAG | (inst[insts[0]].shape_kind << PBRS_TLAS_LEAF_KIND_SHIFT) | 1u;
             return {idx, 1u};
         }
         size_t num_all = insts.size();
@@ -415,15 +416,27 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
         pm.height = root.second;
         pm.n_nodes = (uint32_t)hs->blas_nodes.size() - node0;
         max_blas_height = std::max(max_blas_height, pm.height);
-        hs->meshes.push_back(pm);
+        bool flat_ok = true;
         for (const Tri& t : tris) {
             // `let (i, k, j) = tri.index_triple` (blas.rs:162): vertex order read by the mesh is (i, 3rd, 2nd)
             uint32_t v0 = t.i, v1 = t.k, v2 = t.j;
+            V3 p0 = v3p(m.positions + 3 * v0), p1 = v3p(m.positions + 3 * v1), p2 = v3p(m.positions + 3 * v2);
             pbrs_tri_verts tv{};
             set3(tv.p0, m.positions + 3 * v0);
             set3(tv.p1, m.positions + 3 * v1);
             set3(tv.p2, m.positions + 3 * v2);
-            tv.orig = t.orig;
+            // `(p0 - p1).cross(p2 - p1).try_hat()` (simple.rs:436; Vec3::try_hat math/src/hcm.rs:118-121)
+            V3 gn{pn_nan(), pn_nan(), pn_nan()};
+            bool has_normal = false;
+            {
+                V3 c = cross3(sub(p0, p1), sub(p2, p1));
+                float inv_length = 1.0f / length(c);
+                if (pn_isfinite(inv_length) && inv_length != 0.0f) {
+                    gn = scale(c, inv_length);
+                    has_normal = true;
+                }
+            }
+            tv.nx = gn.x; tv.ny = gn.y; tv.nz = gn.z;
             hs->tri_verts.push_back(tv);
             pbrs_tri_shade ts{};
             set3(ts.n0, m.normals + 3 * v0);
@@ -432,8 +445,39 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
             ts.uv0[0] = m.uvs[2 * v0]; ts.uv0[1] = m.uvs[2 * v0 + 1];
             ts.uv1[0] = m.uvs[2 * v1]; ts.uv1[1] = m.uvs[2 * v1 + 1];
             ts.uv2[0] = m.uvs[2 * v2]; ts.uv2[1] = m.uvs[2 * v2 + 1];
+            ts.orig = t.orig;
             hs->tri_shade.push_back(ts);
+            // PBRS_MESH_FLAT_SHADING_OK: with n0 == n1 == n2 (bitwise) barycentric_lerp returns that normal for any
+            // finite barycentrics ((a-c)*b0 + (b-c)*b1 + c = 0 + 0 + c), `facing` only flips its sign, and the
+            // projection / hat / abs(dot) of blas.rs:186-193 are invariant under that flip: the Q22 test is a
+            // property of the triangle.  Evaluated here with the reference's operand order.
+            if (flat_ok) {
+                bool same = std::memcmp(ts.n0, ts.n1, 12) == 0 && std::memcmp(ts.n0, ts.n2, 12) == 0;
+                bool pass = false;
+                if (same && has_normal) {
+                    V3 n0 = v3p(ts.n0);
+                    V3 n = n0;
+                    float inv_n = 1.0f / length(n0);
+                    if (pn_isfinite(inv_n) && inv_n != 0.0f) n = scale(n0, inv_n); else n = gn;  // `.try_hat().unwrap_or(hit.normal)`
+                    float u0 = ts.uv0[0], w0 = ts.uv0[1];
+                    float u1 = ts.uv1[0] - u0, w1 = ts.uv1[1] - w0;
+                    float u2 = ts.uv2[0] - u0, w2 = ts.uv2[1] - w0;
+                    float den = u1 * w2 - u2 * w1;
+                    V3 num = sub(scale(sub(p2, p0), w2), scale(sub(p1, p0), w1));
+                    V3 dpdu{num.x / den, num.y / den, num.z / den};
+                    if (!pn_isfinite(dot3(dpdu, dpdu))) dpdu = sub(p1, p0);
+                    float dn = dot3(dpdu, n);
+                    V3 sn = scale(n, dn);
+                    float n2 = dot3(n, n);
+                    V3 proj{sn.x / n2, sn.y / n2, sn.z / n2};  // projected_onto: self.dot(other) * other / other.norm_squared()
+                    dpdu = normalized(sub(dpdu, proj));
+                    pass = !(pn_abs(dot3(dpdu, n)) >= 1e-3f);
+                }
+                flat_ok = same && pass;
+            }
         }
+        if (flat_ok) pm.flags |= PBRS_MESH_FLAT_SHADING_OK;
+        hs->meshes.push_back(pm);
     }
     // -- analytic shapes
     std::vector<uint32_t> shape_slot(spec->n_shapes, 0);
@@ -494,6 +538,15 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
         pi.shape_kind = spec->shapes[is.shape].kind;
         pi.shape_index = shape_slot[is.shape];
         pi.material = is.material;
+        if (pi.shape_kind == PBRS_SHAPE_MESH) {
+            pi.blas_root = hs->meshes[pi.shape_index].root;
+            pi.mesh_flags = hs->meshes[pi.shape_index].flags;
+        }
+        {
+            static const float kIdentity[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};
+            if (std::memcmp(pi.inv, kIdentity, sizeof kIdentity) == 0 && std::memcmp(pi.fwd, kIdentity, sizeof kIdentity) == 0)
+                pi.flags |= PBRS_INSTANCE_IDENTITY;
+        }
         hs->instances.push_back(pi);
         M4 fwd;
         std::memcpy(fwd.m, is.forward, sizeof fwd.m);
@@ -502,7 +555,7 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
     // -- TLAS
     std::vector<uint32_t> all(spec->n_instances);
     for (uint32_t i = 0; i < spec->n_instances; ++i) all[i] = i;
-    TlasBuilder tb{inst_box, hs->tlas_nodes};
+    TlasBuilder tb{inst_box, hs->instances, hs->tlas_nodes};
     auto troot = tb.build(std::move(all));
     // -- lights (light/src/lib.rs:114-121; areas: sample_shape.rs:252-254, :271-273, :291-293, :306-308)
     for (uint32_t l = 0; l < spec->n_area_lights; ++l) {

@@ -50,7 +50,7 @@ int main(void) {
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
-    assert sizes[:10] == [32, 112, 48, 32, 48, 64, 64, 32, 64, 32]
+    assert sizes[:10] == [32, 128, 48, 32, 48, 64, 64, 32, 64, 32]
     from pbrs_amd import api, spec
     assert sizes[10] == ctypes.sizeof(api.SceneDesc)
     assert sizes[11] == ctypes.sizeof(api.Camera) == 64
