@@ -60,15 +60,15 @@ PN_FN float pn_signum(float x) {
     return pn_sign_negative(x) ? -1.0f : 1.0f;
 }
 /* f32::max / f32::min: IEEE maxNum/minNum — a NaN operand is ignored. */
-PN_FN float pn_max(float a, float b) {
-    if (b != b) return a;
-    if (a != a) return b;
-    return a > b ? a : b;
+PN_FN float pn_max(float a, float b) { /* select chain (no branches): same values as the early-return form */
+    float m = a > b ? a : b;
+    m = (a != a) ? b : m;
+    return (b != b) ? a : m;
 }
 PN_FN float pn_min(float a, float b) {
-    if (b != b) return a;
-    if (a != a) return b;
-    return a < b ? a : b;
+    float m = a < b ? a : b;
+    m = (a != a) ? b : m;
+    return (b != b) ? a : m;
 }
 /* f32::clamp(lo, hi) (NaN stays NaN). */
 PN_FN float pn_clamp(float x, float lo, float hi) {

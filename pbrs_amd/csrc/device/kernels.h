@@ -32,6 +32,7 @@ struct PathState {
     float* nb[3];     // beta at the time of the estimate
     float* nscale;    // 1 / light_pdf
     uint32_t* nmode;  // 0 area (sum of the two MIS terms), 1 delta, 2 env
+    uint8_t* occ[2];  // written by k_shadow: 1 = the ray is occluded
 };
 #define PBRS_STATE_WORDS 47
 
@@ -112,38 +113,69 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 }
 
 // ---- extend ----------------------------------------------------------------------------------------------------
+// Wave-level work fetch for the persistent traversal kernels: lanes with `need` take consecutive items
+// [base, base + popc) from a device counter with one atomicAdd per wave.  Returns the lane's item index
+// (only meaningful where need) and the wave-uniform end of the range taken.
+PD uint32_t wave_fetch(bool need, uint32_t* next, uint32_t& range_end) {
+    uint64_t mask = __ballot(need);
+    uint32_t total = (uint32_t)__popcll(mask);
+    int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(next, total);
+    base = __shfl(base, leader, 64);
+    range_end = base + total;
+    return base + lane_prefix(mask);
+}
+// Refill when fewer than this many of a wave's 64 lanes still hold a ray (Aila-Laine style replacement of
+// terminated rays: incoherent rays finish after very different node counts, and a wave costs its slowest lane).
+#define PBRS_REFILL_BELOW 40
+
+// Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
+// handed a new ray at the next refill, the walks of the other lanes continue where they were.
 template <bool STATS>
 __global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t n_direct,
-                                               GlobalCounters* gc) {
+                                               uint32_t* next, GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n = queue ? *count : n_direct;
-    bool valid = i < n;
+    const uint32_t n = queue ? *count : n_direct;
+    LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
     Cnt<STATS> cnt;
     cnt.init();
-    uint32_t nhit = 0;
-    if (valid) {
-        uint32_t slot = queue ? queue[i] : i;
-        f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
-        LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
-        Hit h;
-        tlas_closest<STATS>(S, o, d, pn_inf(), stk, h, cnt);
-        nhit = h.inst != 0xffffffffu ? 1u : 0u;
-        st.ht[slot] = h.t;
-        st.hinst[slot] = h.inst;
-        st.hprim[slot] = h.prim;
-        st.hb1[slot] = h.b1;
-        st.hb2[slot] = h.b2;
+    uint32_t nrays = 0, nhit = 0;
+    ClosestWalk<STATS> walk;
+    uint32_t slot = 0;
+    bool active = false, exhausted = false;
+    for (;;) {
+        uint64_t am = __ballot(active);
+        if (!exhausted && __popcll(am) < PBRS_REFILL_BELOW) {
+            uint32_t range_end;
+            uint32_t idx = wave_fetch(!active, next, range_end);
+            if (!active && idx < n) {
+                slot = queue ? queue[idx] : idx;
+                f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
+                walk.start(S, o, d, pn_inf(), stk);
+                active = true;
+                nrays++;
+            }
+            exhausted = range_end >= n;
+            am = __ballot(active);
+        }
+        if (am == 0) break;
+        if (active) {
+            if (walk.node_phase(S, stk, cnt)) {
+                walk.leaf_phase(S, cnt);
+            } else {
+                const Hit& h = walk.best;
+                nhit += h.inst != 0xffffffffu ? 1u : 0u;
+                st.ht[slot] = h.t;
+                st.hinst[slot] = h.inst;
+                st.hprim[slot] = h.prim;
+                st.hb1[slot] = h.b1;
+                st.hb2[slot] = h.b2;
+                active = false;
+            }
+        }
     }
-#ifdef PBRS_TAIL_PROBE  // developer probe: wave-level max vs sum of per-lane node counts (tail divergence)
-    if (STATS) {
-        uint32_t mine = valid ? cnt.c.tlas_nodes + cnt.c.blas_nodes : 0u, mx = mine;
-        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
-        cnt.c.quads = (threadIdx.x & 63u) == 0 ? mx * 64u : 0u;
-        cnt.c.disks = mine;
-    }
-#endif
-    flush_counters<STATS>(cnt, gc, valid, 1u, nhit);
+    flush_counters<STATS>(cnt, gc, true, nrays, nhit);
 }
 
 PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:224-232, BETA = 2, nf = ng = 1
@@ -155,11 +187,11 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 // ---- shade -----------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* queue,
                                               const uint32_t* count, uint32_t n_direct, uint32_t* queue_out, uint32_t* count_out,
-                                              uint32_t* shadow_queue, uint32_t* shadow_count) {
+                                              uint32_t* shadow_queue, uint32_t* shadow_count, uint32_t* nee_queue, uint32_t* nee_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = queue ? *count : n_direct;
     bool valid = i < n;
-    bool alive = false, want_shadow = false;
+    bool alive = false, want_shadow = false, cast0 = false, cast1 = false;
     uint32_t slot = 0;
     if (valid) {
         slot = queue ? queue[i] : i;
@@ -256,6 +288,8 @@ __global__ void __launch_bounds__(256) k_shade(DevScene S, PathState st, RenderC
                 }
                 if (v1.t_max >= 0.0f || v2.t_max >= 0.0f) {
                     want_shadow = true;
+                    cast0 = v1.t_max >= 0.0f;
+                    cast1 = v2.t_max >= 0.0f;
                     for (int r = 0; r < 3; ++r) {
                         st.so[0][r][slot] = comp(v1.o, r);
                         st.sd[0][r][slot] = comp(v1.d, r);
@@ -307,53 +341,90 @@ __global__ void __launch_bounds__(256) k_shade(DevScene S, PathState st, RenderC
     }
     uint32_t p = wave_append(alive, count_out);
     if (alive) queue_out[p] = slot;
-    uint32_t ps = wave_append(want_shadow, shadow_count);
-    if (want_shadow) shadow_queue[ps] = slot;
+    // one shadow-queue entry per ray to cast (bit 31 = which of the path's two), one nee-queue entry per path
+    uint32_t pn = wave_append(want_shadow, nee_count);
+    if (want_shadow) nee_queue[pn] = slot;
+    uint32_t p0 = wave_append(cast0, shadow_count);
+    if (cast0) shadow_queue[p0] = slot;
+    uint32_t p1 = wave_append(cast1, shadow_count);
+    if (cast1) shadow_queue[p1] = slot | 0x80000000u;
 }
 
 // ---- shadow ----------------------------------------------------------------------------------------------------
+// One work item per shadow ray (persistent, same refill scheme as k_extend); writes one occlusion byte.
 template <bool STATS>
-__global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, GlobalCounters* gc) {
+__global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t* next,
+                                               GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool valid = i < *count;
+    const uint32_t n = *count;
+    LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
-    if (valid) {
-        uint32_t slot = queue[i];
-        LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
-        bool cast[2], occ[2];
-        for (int r = 0; r < 2; ++r) {
-            float tm = st.stmax[r][slot];
-            cast[r] = tm >= 0.0f;
-            occ[r] = false;
-            if (cast[r]) {
+    AnyWalk<STATS> walk;
+    uint32_t item = 0;
+    bool active = false, exhausted = false;
+    for (;;) {
+        uint64_t am = __ballot(active);
+        if (!exhausted && __popcll(am) < PBRS_REFILL_BELOW) {
+            uint32_t range_end;
+            uint32_t idx = wave_fetch(!active, next, range_end);
+            if (!active && idx < n) {
+                item = queue[idx];
+                uint32_t slot = item & 0x7fffffffu, r = item >> 31;
                 f3 o = mk3(st.so[r][0][slot], st.so[r][1][slot], st.so[r][2][slot]);
                 f3 d = mk3(st.sd[r][0][slot], st.sd[r][1][slot], st.sd[r][2][slot]);
-                occ[r] = tlas_any<STATS>(S, o, d, tm, stk, cnt);
+                walk.start(S, o, d, st.stmax[r][slot], stk);
+                active = true;
                 nrays++;
             }
+            exhausted = range_end >= n;
+            am = __ballot(active);
         }
-        f3 c1 = mk3(st.sc[0][0][slot], st.sc[0][1][slot], st.sc[0][2][slot]);
-        f3 c2 = mk3(st.sc[1][0][slot], st.sc[1][1][slot], st.sc[1][2][slot]);
-        uint32_t mode = st.nmode[slot];
-        f3 one;
-        if (mode == 0) {  // directlighting.rs:193, :219: radiance_d += term, in this order
-            one = gray(0.0f);
-            if (cast[0] && !occ[0]) one = one + c1;
-            if (cast[1] && !occ[1]) one = one + c2;
-        } else if (mode == 1) {
-            one = occ[0] ? gray(0.0f) : c1;
-        } else {
-            one = occ[0] ? c2 : c1;
+        if (am == 0) break;
+        if (active) {
+            bool done = false, occluded = false;
+            if (walk.node_phase(S, stk, cnt)) {
+                occluded = walk.leaf_phase(S, cnt);
+                done = occluded;
+            } else {
+                done = true;
+            }
+            if (done) {
+                st.occ[item >> 31][item & 0x7fffffffu] = occluded ? 1 : 0;
+                active = false;
+            }
         }
-        f3 nb = mk3(st.nb[0][slot], st.nb[1][slot], st.nb[2][slot]);
-        f3 L = ld_col(st.lr, st.lg, st.lb, slot);
-        L = L + cmul(nb, one * st.nscale[slot]);  // directlighting.rs:98, pathintegrator.rs:35
-        st_col(st.lr, st.lg, st.lb, slot, L);
     }
-    flush_counters<STATS>(cnt, gc, valid, nrays, 0u);
+    flush_counters<STATS>(cnt, gc, true, nrays, 0u);
+}
+
+// The radiance add of uniform_sample_one_light / path_integrator for paths whose estimate had to wait for
+// visibility: Ld terms in the reference's order (directlighting.rs:193, :219), * n_lights (:98), * beta
+// (pathintegrator.rs:35).
+__global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_t* queue, const uint32_t* count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *count) return;
+    uint32_t slot = queue[i];
+    bool cast0 = st.stmax[0][slot] >= 0.0f, cast1 = st.stmax[1][slot] >= 0.0f;
+    bool occ0 = cast0 && st.occ[0][slot] != 0, occ1 = cast1 && st.occ[1][slot] != 0;
+    f3 c1 = mk3(st.sc[0][0][slot], st.sc[0][1][slot], st.sc[0][2][slot]);
+    f3 c2 = mk3(st.sc[1][0][slot], st.sc[1][1][slot], st.sc[1][2][slot]);
+    uint32_t mode = st.nmode[slot];
+    f3 one;
+    if (mode == 0) {
+        one = gray(0.0f);
+        if (cast0 && !occ0) one = one + c1;
+        if (cast1 && !occ1) one = one + c2;
+    } else if (mode == 1) {
+        one = occ0 ? gray(0.0f) : c1;
+    } else {
+        one = occ0 ? c2 : c1;
+    }
+    f3 nb = mk3(st.nb[0][slot], st.nb[1][slot], st.nb[2][slot]);
+    f3 L = ld_col(st.lr, st.lg, st.lb, slot);
+    L = L + cmul(nb, one * st.nscale[slot]);
+    st_col(st.lr, st.lg, st.lb, slot, L);
 }
 
 // ---- accumulate / finalize -----------------------------------------------------------------------------------------

@@ -56,12 +56,13 @@ PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
     if (!R.fast) return slab_test(nmin(n), nmax(n), R.o, R.d, t_max);
     float t0x = qdiv(n.min[0] - R.o.x, R.rx), t0y = qdiv(n.min[1] - R.o.y, R.ry), t0z = qdiv(n.min[2] - R.o.z, R.rz);
     float t1x = qdiv(n.max[0] - R.o.x, R.rx), t1y = qdiv(n.max[1] - R.o.y, R.ry), t1z = qdiv(n.max[2] - R.o.z, R.rz);
-    float lox = sse_min(t0x, t1x), loy = sse_min(t0y, t1y), loz = sse_min(t0z, t1z);
-    float hix = sse_max(t0x, t1x), hiy = sse_max(t0y, t1y), hiz = sse_max(t0z, t1z);
-    float lo_el = sse_max(sse_max(lox, loz), sse_max(loy, loz));
-    float hi_el = sse_min(sse_min(hix, hiz), sse_min(hiy, hiz));
-    float t_low = pn_max(lo_el, 0.0f);
-    float t_high = pn_min(hi_el, t_max);
+    // Inside the guarded range every quotient is finite, so the SSE / f32::max conventions of the reference reduce
+    // to plain min/max (they differ only on NaN operands and on the sign of a zero, which no comparison sees):
+    // v_min_f32 / v_max_f32 / v_min3 / v_max3 instead of compare+select chains.
+    float lo_el = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+    float hi_el = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+    float t_low = __builtin_fmaxf(lo_el, 0.0f);
+    float t_high = __builtin_fminf(hi_el, t_max);  // minNum: a NaN extent is ignored, as f32::min does
     return t_low <= t_high;
 }
 
@@ -76,7 +77,8 @@ PD RaySpace enter_instance(const DevScene& S, const pbrs_instance& in, const Ray
     return make_space(oo, od, S.fast_slab != 0);
 }
 
-// Closest hit.  Semantics kept from the reference:
+// Closest hit, as a resumable walk (one lane = one ray; the kernel interleaves many walks per lane, see
+// k_extend).  Semantics kept from the reference:
 //  * TLAS: left subtree, then right, ray.t_max lowered to the left result (bvh.rs:84-88) == pop order
 //    i+1 before a, box test at pop time against the current t_max.
 //  * a candidate replaces the best when !(best.t < cand.t) (bvh.rs:94-98).
@@ -88,29 +90,41 @@ PD RaySpace enter_instance(const DevScene& S, const pbrs_instance& in, const Ray
 // Known deviation: ray.t_max is never RAISED by such an overshoot; observable only on
 // bit-identical t from two instances (oracle counter tlas_ties).
 template <bool STATS>
-PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
-    best.t = pn_inf();
-    best.inst = 0xffffffffu;
-    best.prim = 0;
-    best.b1 = best.b2 = 0.0f;
-    bool have = false;
-    const RaySpace W = make_space(o, d, S.fast_slab != 0);
-    RaySpace B = W;
-    bool in_blas = false;
-    int sp = 0, blas_base = 0;
-    uint32_t cur_inst = 0, mesh_flags = 0;
-    float lt = 0.0f;      // the cloned ray's t_max inside intersect_bvh
-    float mt = pn_inf();  // outer_hit.ray_t
-    uint32_t mprim = 0;
-    float mb1 = 0.0f, mb2 = 0.0f;
-    stk.put(sp++, 0u);
-    for (;;) {
-        bool leaf = false;
-        pbrs_node node;
-        uint32_t ni = 0;
-        while (!leaf) {
+struct ClosestWalk {
+    RaySpace W, C;  // world ray; C = the space the lane is walking in (W in the TLAS, the instance's ray in a BLAS).
+                    // One box-test call on C serves lanes in either tree: no branch duplicates the test.
+    Hit best;
+    float t_max, lt, mt, mb1, mb2;  // lt: the cloned ray's t_max inside intersect_bvh; mt: outer_hit.ray_t
+    uint32_t mprim, cur_inst, mesh_flags, ni;
+    int sp, blas_base;
+    bool have, in_blas;
+    pbrs_node node;  // the leaf held between node_phase and leaf_phase
+
+    PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
+        W = make_space(o, d, S.fast_slab != 0);
+        C = W;
+        best.t = pn_inf();
+        best.inst = 0xffffffffu;
+        best.prim = 0;
+        best.b1 = best.b2 = 0.0f;
+        have = false;
+        in_blas = false;
+        t_max = tmax;
+        lt = 0.0f;
+        mt = pn_inf();
+        mprim = cur_inst = mesh_flags = ni = 0;
+        mb1 = mb2 = 0.0f;
+        blas_base = 0;
+        stk.put(0, 0u);
+        sp = 1;
+    }
+
+    // Pops and box-tests nodes until the lane holds primitives to test (returns true) or the walk is over (false).
+    PD bool node_phase(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        for (;;) {
             if (in_blas && sp == blas_base) {  // intersect_bvh returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
                 in_blas = false;
+                C = W;
                 if (mt < pn_inf()) {
                     CNT(instance_hits);
                     if (!have || !(best.t < mt)) {
@@ -124,29 +138,22 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
                     }
                 }
             }
-            if (sp == 0) break;
+            if (sp == 0) return false;
             ni = stk.get(--sp);
             node = load_node((in_blas ? S.blas : S.tlas) + ni);
-            bool pass;
-            if (in_blas) {
-                CNT(blas_nodes);
-                pass = slab_rs(node, B, lt);
-            } else {
-                CNT(tlas_nodes);
-                pass = slab_rs(node, W, t_max);
+            if (STATS) {
+                if (in_blas) CNT(blas_nodes);
+                else CNT(tlas_nodes);
             }
-            if (!pass) continue;
+            if (!slab_rs(node, C, in_blas ? lt : t_max)) continue;
             if (in_blas) {
-                if (node.b & PBRS_LEAF_FLAG) {
-                    leaf = true;
-                } else {
-                    uint32_t axis = node.b & 3u;
-                    uint32_t left = ni + 1, right = node.a;
-                    bool left_first = comp(B.d, (int)axis) > 0.0f;
-                    stk.put(sp++, left_first ? right : left);
-                    stk.put(sp++, left_first ? left : right);
-                    lt = mt;
-                }
+                if (node.b & PBRS_LEAF_FLAG) return true;
+                uint32_t axis = node.b & 3u;
+                uint32_t left = ni + 1, right = node.a;
+                bool left_first = comp(C.d, (int)axis) > 0.0f;
+                stk.put(sp++, left_first ? right : left);
+                stk.put(sp++, left_first ? left : right);
+                lt = mt;
             } else if (!(node.b & PBRS_LEAF_FLAG)) {
                 stk.put(sp++, node.a);
                 stk.put(sp++, ni + 1);
@@ -154,7 +161,7 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
                 // Instance::intersect of a mesh (instance.rs:50-53): enter its BLAS without leaving the node loop
                 const pbrs_instance& in = S.inst[node.a];
                 CNT(instances);
-                B = enter_instance(S, in, W);
+                C = enter_instance(S, in, W);
                 in_blas = true;
                 blas_base = sp;
                 cur_inst = node.a;
@@ -163,10 +170,13 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
                 mt = pn_inf();
                 stk.put(sp++, in.blas_root);
             } else {
-                leaf = true;
+                return true;
             }
         }
-        if (!leaf) break;
+    }
+
+    // Tests the primitives of the held leaf: the triangles of a BLAS leaf, or the analytic shape of a TLAS leaf.
+    PD void leaf_phase(const DevScene& S, Cnt<STATS>& cnt) {
         if (in_blas) {
             uint32_t count = node.b & ~PBRS_LEAF_FLAG;
             for (uint32_t k = 0; k < count; ++k) {
@@ -174,7 +184,7 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
                 pbrs_tri_verts tv = load_tri(S.tv + ti);
                 CNT(triangles);
                 TriHit h;
-                if (!mesh_tri_hit(tv, B.o, B.d, lt, h)) continue;
+                if (!mesh_tri_hit(tv, C.o, C.d, lt, h)) continue;
                 CNT(tri_shading);
                 // The reference builds the shading frame of every geometric hit (blas.rs:166-206) and drops the
                 // hit when the tangent check fails (Q22).  Only a hit that would replace outer_hit can change the
@@ -182,7 +192,7 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
                 if (!(h.t < mt)) continue;
                 if (!(mesh_flags & PBRS_MESH_FLAT_SHADING_OK)) {
                     f3 n, dpdu;
-                    if (!mesh_tri_shading(tv, S.ts[ti], B.d, h, n, dpdu)) continue;
+                    if (!mesh_tri_shading(tv, S.ts[ti], C.d, h, n, dpdu)) continue;
                 }
                 mt = h.t;
                 mprim = ti;
@@ -190,13 +200,13 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
                 mb2 = h.b2;
             }
             lt = mt;
-            continue;
+            return;
         }
-        // TLAS leaf holding an analytic shape: Instance::intersect (instance.rs:50-67)
+        // Instance::intersect of an analytic shape (instance.rs:50-67)
         const pbrs_instance& in = S.inst[node.a];
         CNT(instances);
-        f3 oo = xf_apply(in.inv, o, 1.0f);
-        f3 od = xf_apply(in.inv, d, 0.0f);
+        f3 oo = xf_apply(in.inv, W.o, 1.0f);
+        f3 od = xf_apply(in.inv, W.d, 0.0f);
         const float* p = S.shapes[in.shape_index].p;
         float t = 0.0f, b1 = 0.0f, b2 = 0.0f;
         bool hit = false;
@@ -235,7 +245,7 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
                 break;
             }
         }
-        if (!hit) continue;
+        if (!hit) return;
         CNT(instance_hits);
         if (!have || !(best.t < t)) {
             have = true;
@@ -247,7 +257,7 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
             t_max = t;
         }
     }
-}
+};
 
 // Any hit: BvhNode::occludes (bvh.rs:105-113), Instance::occludes (instance.rs:68-72), intersect_bvh_pred
 // (blas.rs:478-495).  A pure OR over the leaves reached through intersecting boxes with a fixed extent:
@@ -255,92 +265,109 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
 // are visited near-first (by the sign of the ray direction on the split axis), which reaches an occluder
 // sooner than the reference's left-first recursion.
 template <bool STATS>
-PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
-    const RaySpace W = make_space(o, d, S.fast_slab != 0);
-    RaySpace B = W;
-    bool in_blas = false;
-    int sp = 0, blas_base = 0;
-    stk.put(sp++, 0u);
-    for (;;) {
-        bool leaf = false;
-        pbrs_node node;
-        uint32_t ni = 0;
-        while (!leaf) {
-            if (in_blas && sp == blas_base) in_blas = false;
-            if (sp == 0) break;
+struct AnyWalk {
+    RaySpace W, C;
+    float t_max;
+    uint32_t ni;
+    int sp, blas_base;
+    bool in_blas;
+    pbrs_node node;
+
+    PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
+        W = make_space(o, d, S.fast_slab != 0);
+        C = W;
+        t_max = tmax;
+        in_blas = false;
+        blas_base = 0;
+        ni = 0;
+        stk.put(0, 0u);
+        sp = 1;
+    }
+    PD bool node_phase(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        for (;;) {
+            if (in_blas && sp == blas_base) {
+                in_blas = false;
+                C = W;
+            }
+            if (sp == 0) return false;
             ni = stk.get(--sp);
             node = load_node((in_blas ? S.blas : S.tlas) + ni);
-            bool pass;
-            if (in_blas) {
-                CNT(blas_nodes);
-                pass = slab_rs(node, B, t_max);
-            } else {
-                CNT(tlas_nodes);
-                pass = slab_rs(node, W, t_max);
+            if (STATS) {
+                if (in_blas) CNT(blas_nodes);
+                else CNT(tlas_nodes);
             }
-            if (!pass) continue;
+            if (!slab_rs(node, C, t_max)) continue;
             if (in_blas) {
-                if (node.b & PBRS_LEAF_FLAG) {
-                    leaf = true;
-                } else {
-                    uint32_t axis = node.b & 3u;
-                    uint32_t left = ni + 1, right = node.a;
-                    bool left_first = comp(B.d, (int)axis) > 0.0f;
-                    stk.put(sp++, left_first ? right : left);
-                    stk.put(sp++, left_first ? left : right);
-                }
+                if (node.b & PBRS_LEAF_FLAG) return true;
+                uint32_t axis = node.b & 3u;
+                uint32_t left = ni + 1, right = node.a;
+                bool left_first = comp(C.d, (int)axis) > 0.0f;
+                stk.put(sp++, left_first ? right : left);
+                stk.put(sp++, left_first ? left : right);
             } else if (!(node.b & PBRS_LEAF_FLAG)) {
                 stk.put(sp++, node.a);
                 stk.put(sp++, ni + 1);
             } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
                 const pbrs_instance& in = S.inst[node.a];
                 CNT(instances);
-                B = enter_instance(S, in, W);
+                C = enter_instance(S, in, W);
                 in_blas = true;
                 blas_base = sp;
                 stk.put(sp++, in.blas_root);
             } else {
-                leaf = true;
+                return true;
             }
         }
-        if (!leaf) return false;
+    }
+    // true = occluded
+    PD bool leaf_phase(const DevScene& S, Cnt<STATS>& cnt) {
         if (in_blas) {
             uint32_t count = node.b & ~PBRS_LEAF_FLAG;
             for (uint32_t k = 0; k < count; ++k) {
                 pbrs_tri_verts tv = load_tri(S.tv + node.a + k);
                 CNT(triangles);
-                if (mesh_tri_pred(tv, B.o, B.d, t_max)) return true;
+                if (mesh_tri_pred(tv, C.o, C.d, t_max)) return true;
             }
-            continue;
+            return false;
         }
         const pbrs_instance& in = S.inst[node.a];
         CNT(instances);
-        f3 oo = xf_apply(in.inv, o, 1.0f);
-        f3 od = xf_apply(in.inv, d, 0.0f);
+        f3 oo = xf_apply(in.inv, W.o, 1.0f);
+        f3 od = xf_apply(in.inv, W.d, 0.0f);
         const float* p = S.shapes[in.shape_index].p;
-        bool occ = false;
         switch (in.shape_kind) {
             case PBRS_SHAPE_SPHERE:
                 CNT(spheres);
-                occ = sphere_occludes(ld3(p), p[3], oo, od, t_max);
-                break;
+                return sphere_occludes(ld3(p), p[3], oo, od, t_max);
             case PBRS_SHAPE_QUAD:
                 CNT(quads);
-                occ = quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
-                break;
+                return quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
             case PBRS_SHAPE_CUBOID:  // Q14: the bbox slab test
                 CNT(cuboids);
-                occ = slab_test(ld3(p), ld3(p + 3), oo, od, t_max);
-                break;
+                return slab_test(ld3(p), ld3(p + 3), oo, od, t_max);
             case PBRS_SHAPE_DISK:
                 CNT(disks);
-                occ = disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od);
-                break;
+                return disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od);
             default:
                 CNT(triangles);
-                occ = tri_pred(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
-                break;
+                return tri_pred(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
         }
-        if (occ) return true;
     }
+};
+
+// One ray start to finish (parity harness; the pipeline kernels interleave walks instead).
+template <bool STATS>
+PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
+    ClosestWalk<STATS> w;
+    w.start(S, o, d, t_max, stk);
+    while (w.node_phase(S, stk, cnt)) w.leaf_phase(S, cnt);
+    best = w.best;
+}
+template <bool STATS>
+PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
+    AnyWalk<STATS> w;
+    w.start(S, o, d, t_max, stk);
+    while (w.node_phase(S, stk, cnt))
+        if (w.leaf_phase(S, cnt)) return true;
+    return false;
 }

@@ -20,6 +20,7 @@ namespace {
 
 constexpr uint32_t kBlock = 256;
 constexpr uint32_t kMaxDepth = 64;
+constexpr uint32_t kPersistentBlocks = 256 * 6;  // 256 CUs x up to 6 resident 256-thread blocks (VGPR/LDS permitting)
 constexpr size_t kLdsBytesPerCU = 160 * 1024;
 
 struct StageEvent {
@@ -45,8 +46,8 @@ struct pbrs_ctx {
     size_t cap_slots = 0, cap_pixels = 0;
     void* state_mem = nullptr;
     PathState st{};
-    uint32_t* queues = nullptr;   // 3 * cap_slots: ping, pong, shadow
-    uint32_t* counters = nullptr; // 2 * (kMaxDepth + 2)
+    uint32_t* queues = nullptr;   // 5 * cap_slots: ping, pong, nee, shadow rays (2 per path)
+    uint32_t* counters = nullptr; // 5 * (kMaxDepth + 2): act, shc, nee, extend work heads, shadow work heads
     float* sum = nullptr;         // 3 * cap_pixels, planar
     float* rgb_dev = nullptr;     // 3 * cap_pixels, row-major (for the host-output variant)
     GlobalCounters* gcnt = nullptr;  // [0] extend, [1] shadow
@@ -114,7 +115,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         c->state_mem = nullptr;
         c->queues = nullptr;
         size_t col = ((n_slots * 4 + 255) / 256) * 256;
-        const size_t n_cols = 6 + 3 + 3 + 2 /*rng*/ + 1 + 5 + 18 + 2 + 3 + 1 + 1;
+        const size_t n_cols = 6 + 3 + 3 + 2 /*rng*/ + 1 + 5 + 18 + 2 + 3 + 1 + 1 + 1 /*occ bytes*/;
         HIPCHK(c, hipMalloc(&c->state_mem, col * n_cols));
         char* base = static_cast<char*>(c->state_mem);
         size_t k = 0;
@@ -138,7 +139,10 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         for (int a = 0; a < 3; ++a) s.nb[a] = colf();
         s.nscale = colf();
         s.nmode = colu();
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->queues), 3 * n_slots * sizeof(uint32_t)));
+        s.occ[0] = reinterpret_cast<uint8_t*>(base + col * k);
+        s.occ[1] = s.occ[0] + n_slots;  // the column holds 4 * n_slots bytes
+        k += 1;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->queues), 5 * n_slots * sizeof(uint32_t)));
         c->cap_slots = n_slots;
     }
     if (n_pixels > c->cap_pixels) {
@@ -225,11 +229,18 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     rc.pass_first_sample = first;
     rc.n_slots = N;
     const uint32_t grid = (N + kBlock - 1) / kBlock;
-    uint32_t* act = c->counters;                  // act[b]: paths entering bounce b (b >= 1)
-    uint32_t* shc = c->counters + (kMaxDepth + 2);  // shc[b]: paths with pending shadow rays at bounce b
+    // persistent traversal kernels: enough blocks to fill the chip, each pulls work until the queue is empty
+    const uint32_t pgrid = grid < kPersistentBlocks ? grid : kPersistentBlocks;
+    const uint32_t stride = kMaxDepth + 2;
+    uint32_t* act = c->counters;                 // act[b]: paths entering bounce b (b >= 1)
+    uint32_t* shc = c->counters + stride;        // shc[b]: shadow rays cast at bounce b
+    uint32_t* nee = c->counters + 2 * stride;    // nee[b]: paths whose light estimate waits for visibility
+    uint32_t* xhead = c->counters + 3 * stride;  // work-fetch heads of k_extend / k_shadow per bounce
+    uint32_t* shead = c->counters + 4 * stride;
     uint32_t* q[2] = {c->queues, c->queues + c->cap_slots};
-    uint32_t* shq = c->queues + 2 * c->cap_slots;
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, 2 * (kMaxDepth + 2) * sizeof(uint32_t), c->stream));
+    uint32_t* neeq = c->queues + 2 * c->cap_slots;
+    uint32_t* shq = c->queues + 3 * c->cap_slots;
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, 5 * stride * sizeof(uint32_t), c->stream));
     if (tm.begin(0)) return fail(c, PBRS_E_DEVICE, "event record failed");
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, c->st, rc);
     tm.end();
@@ -238,19 +249,20 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         const uint32_t* qin = b == 0 ? nullptr : q[b & 1];
         if (tm.begin(1)) return fail(c, PBRS_E_DEVICE, "event record failed");
         if (stats)
-            hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, c->gcnt);
+            hipLaunchKernelGGL(k_extend<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, xhead + b, c->gcnt);
         else
-            hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, c->gcnt);
+            hipLaunchKernelGGL(k_extend<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, xhead + b, c->gcnt);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
         hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], act + b + 1, shq,
-                           shc + b);
+                           shc + b, neeq, nee + b);
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
         if (stats)
-            hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, shc + b, c->gcnt + 1);
+            hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, shc + b, shead + b, c->gcnt + 1);
         else
-            hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, shc + b, c->gcnt + 1);
+            hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, shc + b, shead + b, c->gcnt + 1);
+        hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(kBlock), 0, c->stream, c->st, neeq, nee + b);
         tm.end();
     }
     if (tm.begin(4)) return fail(c, PBRS_E_DEVICE, "event record failed");
@@ -342,7 +354,7 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     c->stream = c->own_stream;
     c->total_ev.resize(2);
     if (hipEventCreate(&c->total_ev[0]) != hipSuccess || hipEventCreate(&c->total_ev[1]) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->counters), 2 * (kMaxDepth + 2) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->counters), 5 * (kMaxDepth + 2) * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) != hipSuccess) {
         delete c;
         return PBRS_E_DEVICE;
