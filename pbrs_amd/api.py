@@ -105,7 +105,8 @@ def gpu_lib():
     """Loads the HIP library. Raises (never falls back) when it is absent or cannot be loaded."""
     global _gpu
     if _gpu is None:
-        path = lib_paths()[1]
+        # PBRS_GPU_LIB: developer override to A/B two builds of the HIP library in one session (tools/ablate.sh)
+        path = os.environ.get("PBRS_GPU_LIB") or lib_paths()[1]
         if not os.path.exists(path):
             raise PbrsError(f"{path} is missing: the HIP extension must be built (make -C pbrs_amd/csrc); there is no CPU fallback")
         L = C.CDLL(path)

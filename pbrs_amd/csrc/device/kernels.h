@@ -113,23 +113,57 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 }
 
 // ---- extend ----------------------------------------------------------------------------------------------------
-// Wave-level work fetch for the persistent traversal kernels: lanes with `need` take consecutive items
-// [base, base + popc) from a device counter with one atomicAdd per wave.  Returns the lane's item index
-// (only meaningful where need) and the wave-uniform end of the range taken.
-PD uint32_t wave_fetch(bool need, uint32_t* next, uint32_t& range_end) {
-    uint64_t mask = __ballot(need);
-    uint32_t total = (uint32_t)__popcll(mask);
+#ifndef PBRS_REFILL_BELOW
+#define PBRS_REFILL_BELOW 40
+#endif
+#ifndef PBRS_CHUNK_MAX
+#define PBRS_CHUNK_MAX 512u
+#endif
+#ifndef PBRS_SHADE_WAVES  // min waves per SIMD asked of the register allocator for k_shade (2nd arg of __launch_bounds__)
+#define PBRS_SHADE_WAVES 3
+#endif
+
+// Work fetch of the persistent traversal kernels.  A wave owns a private range [cur, end) of queue items and hands
+// them to its idle lanes without touching memory; only when the range is empty does its first idle lane take a new
+// chunk from the device-wide head with one atomicAdd (a hot head word serialises at ~10 ns per atomic, so per-refill
+// atomics would throttle the kernel).  All values are wave-uniform.
+struct WaveWork {
+    uint32_t cur, end, chunk;
+    bool exhausted;
+};
+PD WaveWork wave_work_init(uint32_t n) {
+    // small queues (late bounces) get small chunks so that every wave still finds work
+    uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    uint32_t chunk = n / (waves * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > PBRS_CHUNK_MAX ? PBRS_CHUNK_MAX : (chunk & ~63u));
+    return WaveWork{0u, 0u, chunk, false};
+}
+// Lanes with `need` get an item index < n (returned; 0xffffffff = none).  Items left in the wave's range are handed
+// out first; if they do not cover every idle lane a new chunk is taken in the same call, so a refill never leaves
+// lanes idle while the queue still holds work.
+PD uint32_t wave_fetch(WaveWork& w, bool need, uint32_t* head, uint32_t n) {
+    const uint64_t mask = __ballot(need);
+    const uint32_t want = (uint32_t)__popcll(mask), rank = lane_prefix(mask);
+    const uint32_t avail = w.end - w.cur;
+    uint32_t idx = (need && rank < avail) ? w.cur + rank : 0xffffffffu;
+    if (want <= avail) {
+        w.cur += want;
+        return idx;
+    }
+    w.cur = w.end;
+    if (w.exhausted) return idx;
     int leader = __ffsll((unsigned long long)mask) - 1;
     uint32_t base = 0;
-    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(next, total);
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(head, w.chunk);
     base = __shfl(base, leader, 64);
-    range_end = base + total;
-    return base + lane_prefix(mask);
+    const uint32_t lo = base < n ? base : n, hi = base + w.chunk < n ? base + w.chunk : n;
+    if (base + w.chunk >= n) w.exhausted = true;  // nothing beyond this chunk
+    const uint32_t rest = want - avail, got = hi - lo;
+    if (need && rank >= avail && lo + (rank - avail) < hi) idx = lo + (rank - avail);
+    w.cur = lo + (rest < got ? rest : got);
+    w.end = hi;
+    return idx;
 }
-// Refill when fewer than this many of a wave's 64 lanes still hold a ray (Aila-Laine style replacement of
-// terminated rays: incoherent rays finish after very different node counts, and a wave costs its slowest lane).
-#define PBRS_REFILL_BELOW 40
-
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
 // handed a new ray at the next refill, the walks of the other lanes continue where they were.
 template <bool STATS>
@@ -143,20 +177,19 @@ __global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const 
     uint32_t nrays = 0, nhit = 0;
     ClosestWalk<STATS> walk;
     uint32_t slot = 0;
-    bool active = false, exhausted = false;
+    bool active = false;
+    WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t am = __ballot(active);
-        if (!exhausted && __popcll(am) < PBRS_REFILL_BELOW) {
-            uint32_t range_end;
-            uint32_t idx = wave_fetch(!active, next, range_end);
-            if (!active && idx < n) {
+        if (!(work.exhausted && work.cur >= work.end) && __popcll(am) < PBRS_REFILL_BELOW) {
+            uint32_t idx = wave_fetch(work, !active, next, n);
+            if (idx != 0xffffffffu) {
                 slot = queue ? queue[idx] : idx;
                 f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
                 walk.start(S, o, d, pn_inf(), stk);
                 active = true;
                 nrays++;
             }
-            exhausted = range_end >= n;
             am = __ballot(active);
         }
         if (am == 0) break;
@@ -185,9 +218,9 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 }
 
 // ---- shade -----------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* queue,
+__global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* queue,
                                               const uint32_t* count, uint32_t n_direct, uint32_t* queue_out, uint32_t* count_out,
-                                              uint32_t* shadow_queue, uint32_t* shadow_count, uint32_t* nee_queue, uint32_t* nee_count) {
+                                              uint32_t* shadow_queue, uint32_t* nee_queue, unsigned long long* nee_shadow_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = queue ? *count : n_direct;
     bool valid = i < n;
@@ -213,11 +246,25 @@ __global__ void __launch_bounds__(256) k_shade(DevScene S, PathState st, RenderC
         }
         if (has_hit) {
             uint64_t rng = st.rng[slot];
+#ifdef PBRS_ABL_NO_RECON  // timing-only ablation build: skips the Interaction rebuild, results are wrong
+            Isect is;
+            is.pos = o + h.t * d;
+            is.normal = mk3(0.0f, 1.0f, 0.0f);
+            is.wo = -d;
+            is.tangent = mk3(1.0f, 0.0f, 0.0f);
+#else
             Isect is = reconstruct_isect(S, h, o, d);
+#endif
             Bsdf bs = bsdf_new_frame(is, S.bxdfs + mat->first_bxdf, mat->n_bxdfs);
 
             // uniform_sample_one_light, directlighting.rs:58-99
             uint32_t num_lights = S.n_delta + S.n_area + S.has_env;
+#ifdef PBRS_ABL_NO_NEE  // timing-only ablation build (tools/ablate.sh): skips next-event estimation, results are wrong
+            if (num_lights > 0) {
+                for (int k = 0; k < 5; ++k) pn_rng_f32(&rng);
+                num_lights = 0;
+            }
+#endif
             if (num_lights > 0) {
                 float light_pdf = 1.0f / (float)num_lights;
                 float uidx = pn_rng_f32(&rng);
@@ -339,15 +386,45 @@ __global__ void __launch_bounds__(256) k_shade(DevScene S, PathState st, RenderC
         }
         st_col(st.lr, st.lg, st.lb, slot, L);
     }
-    uint32_t p = wave_append(alive, count_out);
-    if (alive) queue_out[p] = slot;
-    // one shadow-queue entry per ray to cast (bit 31 = which of the path's two), one nee-queue entry per path
-    uint32_t pn = wave_append(want_shadow, nee_count);
-    if (want_shadow) nee_queue[pn] = slot;
-    uint32_t p0 = wave_append(cast0, shadow_count);
-    if (cast0) shadow_queue[p0] = slot;
-    uint32_t p1 = wave_append(cast1, shadow_count);
-    if (cast1) shadow_queue[p1] = slot | 0x80000000u;
+    // Stream compaction of the three outputs.  A hot queue tail serialises at ~10 ns per atomic on gfx950, so the
+    // counts are first summed per block through LDS and the tails are bumped by TWO atomics per block: the
+    // next-bounce tail, and one 64-bit add carrying the nee-path count (low half) and the shadow-ray count (high).
+    __shared__ uint32_t s_cnt[4][4];   // [wave][alive, nee, cast0, cast1]
+    __shared__ uint32_t s_base[4];     // block bases: alive, nee, shadow
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t m_alive = __ballot(alive), m_nee = __ballot(want_shadow), m_c0 = __ballot(cast0), m_c1 = __ballot(cast1);
+    if (lane == 0) {
+        s_cnt[wave][0] = (uint32_t)__popcll(m_alive);
+        s_cnt[wave][1] = (uint32_t)__popcll(m_nee);
+        s_cnt[wave][2] = (uint32_t)__popcll(m_c0);
+        s_cnt[wave][3] = (uint32_t)__popcll(m_c1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t_alive = 0, t_nee = 0, t_sh = 0;
+        for (int w = 0; w < 4; ++w) {
+            t_alive += s_cnt[w][0];
+            t_nee += s_cnt[w][1];
+            t_sh += s_cnt[w][2] + s_cnt[w][3];
+        }
+        s_base[0] = t_alive ? atomicAdd(count_out, t_alive) : 0u;
+        unsigned long long packed = 0ull;
+        if (t_nee | t_sh) packed = atomicAdd(nee_shadow_count, ((unsigned long long)t_sh << 32) | (unsigned long long)t_nee);
+        s_base[1] = (uint32_t)packed;
+        s_base[2] = (uint32_t)(packed >> 32);
+    }
+    __syncthreads();
+    uint32_t b_alive = s_base[0], b_nee = s_base[1], b_sh = s_base[2];
+    for (uint32_t w = 0; w < wave; ++w) {
+        b_alive += s_cnt[w][0];
+        b_nee += s_cnt[w][1];
+        b_sh += s_cnt[w][2] + s_cnt[w][3];
+    }
+    if (alive) queue_out[b_alive + lane_prefix(m_alive)] = slot;
+    // one nee-queue entry per path with a pending estimate, one shadow-queue entry per ray to cast (bit 31 = which ray)
+    if (want_shadow) nee_queue[b_nee + lane_prefix(m_nee)] = slot;
+    if (cast0) shadow_queue[b_sh + lane_prefix(m_c0)] = slot;
+    if (cast1) shadow_queue[b_sh + s_cnt[wave][2] + lane_prefix(m_c1)] = slot | 0x80000000u;
 }
 
 // ---- shadow ----------------------------------------------------------------------------------------------------
@@ -356,20 +433,20 @@ template <bool STATS>
 __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t* next,
                                                GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
-    const uint32_t n = *count;
+    const uint32_t n = count[1];  // high half of the packed (nee paths, shadow rays) counter
     LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
     AnyWalk<STATS> walk;
     uint32_t item = 0;
-    bool active = false, exhausted = false;
+    bool active = false;
+    WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t am = __ballot(active);
-        if (!exhausted && __popcll(am) < PBRS_REFILL_BELOW) {
-            uint32_t range_end;
-            uint32_t idx = wave_fetch(!active, next, range_end);
-            if (!active && idx < n) {
+        if (!(work.exhausted && work.cur >= work.end) && __popcll(am) < PBRS_REFILL_BELOW) {
+            uint32_t idx = wave_fetch(work, !active, next, n);
+            if (idx != 0xffffffffu) {
                 item = queue[idx];
                 uint32_t slot = item & 0x7fffffffu, r = item >> 31;
                 f3 o = mk3(st.so[r][0][slot], st.so[r][1][slot], st.so[r][2][slot]);
@@ -378,7 +455,6 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const 
                 active = true;
                 nrays++;
             }
-            exhausted = range_end >= n;
             am = __ballot(active);
         }
         if (am == 0) break;
@@ -404,7 +480,7 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const 
 // (pathintegrator.rs:35).
 __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_t* queue, const uint32_t* count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *count) return;
+    if (i >= count[0]) return;  // low half of the packed (nee paths, shadow rays) counter
     uint32_t slot = queue[i];
     bool cast0 = st.stmax[0][slot] >= 0.0f, cast1 = st.stmax[1][slot] >= 0.0f;
     bool occ0 = cast0 && st.occ[0][slot] != 0, occ1 = cast1 && st.occ[1][slot] != 0;

@@ -233,8 +233,8 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     const uint32_t pgrid = grid < kPersistentBlocks ? grid : kPersistentBlocks;
     const uint32_t stride = kMaxDepth + 2;
     uint32_t* act = c->counters;                 // act[b]: paths entering bounce b (b >= 1)
-    uint32_t* shc = c->counters + stride;        // shc[b]: shadow rays cast at bounce b
-    uint32_t* nee = c->counters + 2 * stride;    // nee[b]: paths whose light estimate waits for visibility
+    // ns[b]: one 64-bit word per bounce: low half = paths whose light estimate waits for visibility, high half = shadow rays
+    unsigned long long* ns = reinterpret_cast<unsigned long long*>(c->counters + stride);
     uint32_t* xhead = c->counters + 3 * stride;  // work-fetch heads of k_extend / k_shadow per bounce
     uint32_t* shead = c->counters + 4 * stride;
     uint32_t* q[2] = {c->queues, c->queues + c->cap_slots};
@@ -255,14 +255,14 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
         hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], act + b + 1, shq,
-                           shc + b, neeq, nee + b);
+                           neeq, ns + b);
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
         if (stats)
-            hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, shc + b, shead + b, c->gcnt + 1);
+            hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b, c->gcnt + 1);
         else
-            hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, shc + b, shead + b, c->gcnt + 1);
-        hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(kBlock), 0, c->stream, c->st, neeq, nee + b);
+            hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b, c->gcnt + 1);
+        hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
         tm.end();
     }
     if (tm.begin(4)) return fail(c, PBRS_E_DEVICE, "event record failed");
