@@ -164,6 +164,16 @@ def main():
         times.update(launches)
         rep = roofline.stage_report(cst, {k: (v / args.steps if k.startswith("ms_") else v // args.steps) for k, v in times.items()})
         dom_name, dom = roofline.dominant(rep)
+        # HBM bytes per launch from the PMC counters cannot be collected in-process (rocprofv3 owns the counters); the
+        # last measured figure for this workload, if any, is read from profiles/ (tools/traffic_from_pmc.py).
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", f"latest_traffic_{args.config}.json")
+        full_size = (W, H, depth) == (scenes.CONFIGS[args.config][2], scenes.CONFIGS[args.config][3], scenes.CONFIGS[args.config][6])
+        if os.path.exists(tpath) and world == 1 and full_size and not args.samples_per_pass:
+            with open(tpath) as f:
+                tk = json.load(f)["kernels"].get(dom["kernel"] + "<false>")
+            if tk:
+                traffic, traffic_src = tk["hbm_total"], os.path.relpath(tpath, ROOT)
         traversal_ms = (stage_ms["ms_extend"] + stage_ms["ms_shadow"]) / args.steps
         traversal_bytes = roofline.extend_bytes(cst) + roofline.shadow_bytes(cst)
         result = {
@@ -187,9 +197,10 @@ def main():
             "frame_mean_radiance": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)],
             "roofline": {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["achieved_GBps"] / roofline.HBM_PEAK_GBS, "traffic": None,
+                "frac": dom["achieved_GBps"] / roofline.HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": dom["bytes_per_launch"], "ms_per_launch": dom["ms_per_launch"], "launches_per_step": dom["launches"],
-                "note": "rank 0's kernels; algorithmic bytes per SURVEY.md §8(d); traffic (PMC) not collected in-process, see profiles/",
+                "note": "rank 0's kernels; achieved = algorithmic bytes (SURVEY.md §8d) / HIP-event time; traffic = HBM bytes per launch from separate "
+                        "rocprofv3 FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled per the gfx950 guide), measured offline, see profiles/",
             },
             "traversal": {"achieved": traversal_bytes / (traversal_ms * 1e-3) / 1e9 if traversal_ms > 0 else 0.0, "unit": "GB/s",
                           "frac": (traversal_bytes / (traversal_ms * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS) if traversal_ms > 0 else 0.0,

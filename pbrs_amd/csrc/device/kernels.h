@@ -392,7 +392,9 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
     __shared__ uint32_t s_cnt[4][4];   // [wave][alive, nee, cast0, cast1]
     __shared__ uint32_t s_base[4];     // block bases: alive, nee, shadow
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint64_t m_alive = __ballot(alive), m_nee = __ballot(want_shadow), m_c0 = __ballot(cast0), m_c1 = __ballot(cast1);
+    const bool both = cast0 && cast1;  // two rays: k_nee_resolve combines them; a lone ray is resolved by the lane that traces it
+    const uint32_t lone = (want_shadow && !both) ? 0x40000000u : 0u;
+    const uint64_t m_alive = __ballot(alive), m_nee = __ballot(both), m_c0 = __ballot(cast0), m_c1 = __ballot(cast1);
     if (lane == 0) {
         s_cnt[wave][0] = (uint32_t)__popcll(m_alive);
         s_cnt[wave][1] = (uint32_t)__popcll(m_nee);
@@ -421,10 +423,10 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
         b_sh += s_cnt[w][2] + s_cnt[w][3];
     }
     if (alive) queue_out[b_alive + lane_prefix(m_alive)] = slot;
-    // one nee-queue entry per path with a pending estimate, one shadow-queue entry per ray to cast (bit 31 = which ray)
-    if (want_shadow) nee_queue[b_nee + lane_prefix(m_nee)] = slot;
-    if (cast0) shadow_queue[b_sh + lane_prefix(m_c0)] = slot;
-    if (cast1) shadow_queue[b_sh + s_cnt[wave][2] + lane_prefix(m_c1)] = slot | 0x80000000u;
+    // one shadow-queue entry per ray to cast (bit 31 = which ray, bit 30 = the path's only ray), one nee-queue entry per two-ray path
+    if (both) nee_queue[b_nee + lane_prefix(m_nee)] = slot;
+    if (cast0) shadow_queue[b_sh + lane_prefix(m_c0)] = slot | lone;
+    if (cast1) shadow_queue[b_sh + s_cnt[wave][2] + lane_prefix(m_c1)] = slot | 0x80000000u | lone;
 }
 
 // ---- shadow ----------------------------------------------------------------------------------------------------
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const 
             uint32_t idx = wave_fetch(work, !active, next, n);
             if (idx != 0xffffffffu) {
                 item = queue[idx];
-                uint32_t slot = item & 0x7fffffffu, r = item >> 31;
+                uint32_t slot = item & 0x3fffffffu, r = item >> 31;
                 f3 o = mk3(st.so[r][0][slot], st.so[r][1][slot], st.so[r][2][slot]);
                 f3 d = mk3(st.sd[r][0][slot], st.sd[r][1][slot], st.sd[r][2][slot]);
                 walk.start(S, o, d, st.stmax[r][slot], stk);
@@ -467,7 +469,28 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const 
                 done = true;
             }
             if (done) {
-                st.occ[item >> 31][item & 0x7fffffffu] = occluded ? 1 : 0;
+                const uint32_t slot = item & 0x3fffffffu, r = item >> 31;
+                if (item & 0x40000000u) {
+                    // the path's only shadow ray: nothing to wait for, finish the estimate here
+                    // (directlighting.rs:193 / :219 / :90-96, then :98 and pathintegrator.rs:35)
+                    f3 cr = mk3(st.sc[r][0][slot], st.sc[r][1][slot], st.sc[r][2][slot]);
+                    uint32_t mode = st.nmode[slot];
+                    f3 one;
+                    if (mode == 0) {
+                        one = gray(0.0f);
+                        if (!occluded) one = one + cr;
+                    } else if (mode == 1) {
+                        one = occluded ? gray(0.0f) : cr;
+                    } else {
+                        one = occluded ? mk3(st.sc[1][0][slot], st.sc[1][1][slot], st.sc[1][2][slot]) : cr;
+                    }
+                    f3 nb = mk3(st.nb[0][slot], st.nb[1][slot], st.nb[2][slot]);
+                    f3 L = ld_col(st.lr, st.lg, st.lb, slot);
+                    L = L + cmul(nb, one * st.nscale[slot]);
+                    st_col(st.lr, st.lg, st.lb, slot, L);
+                } else {
+                    st.occ[r][slot] = occluded ? 1 : 0;
+                }
                 active = false;
             }
         }

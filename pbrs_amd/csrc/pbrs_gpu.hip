@@ -159,6 +159,8 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
 
 size_t lds_bytes(const pbrs_ctx* c) { return (size_t)(c->stack_depth) * kBlock * sizeof(uint32_t); }
 
+uint32_t auto_samples_per_pass(const pbrs_render_params* p);
+
 int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p) {
     if (!cam || !p) return fail(c, PBRS_E_INVALID, "null camera or params");
     if (!c->has_scene) return fail(c, PBRS_E_NO_SCENE, "no scene uploaded");
@@ -174,6 +176,8 @@ int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* 
     if (p->strata_x == 0 || p->strata_y == 0) return fail(c, PBRS_E_INVALID, "zero strata");
     if (p->max_depth > kMaxDepth) return fail(c, PBRS_E_LIMIT, "max_depth above 64");
     if ((uint64_t)p->w * p->h > (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile above 2^28 pixels");
+    // queue entries keep two flag bits next to the slot index
+    if ((uint64_t)p->w * p->h * auto_samples_per_pass(p) >= (1ull << 30)) return fail(c, PBRS_E_LIMIT, "tile x samples_per_pass above 2^30 paths");
     return PBRS_OK;
 }
 

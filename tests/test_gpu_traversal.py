@@ -103,3 +103,41 @@ def test_empty_and_degenerate_batches(gpu_ctx):
     h_ref, occ_ref, _ = OracleScene(sb).intersect(o, d, t)
     h_gpu, occ_gpu = gpu_ctx.intersect(o, d, t)
     assert (h_ref["inst"] == h_gpu["inst"]).all() and (occ_ref == occ_gpu).all()
+
+
+@pytest.mark.parametrize("scale", [1e-9, 1e-3, 1.0, 1e6, 1e13])
+def test_box_test_fallback_ranges(gpu_ctx, scale):
+    """The f64-reciprocal box test is only taken inside its proven range (node coordinates 0 or 2^-20..2^40, ray
+    components in range); scenes and rays outside it must take the reference's literal divisions and still agree bit
+    for bit.  Same geometry at five scales, rays with zero, tiny and huge components."""
+    from pbrs_amd.spec import SceneBuilder, Transform, deg
+    s = np.float32(scale)
+    sb = SceneBuilder()
+    m = sb.lambertian((0.5, 0.5, 0.5))
+    sb.instance(scenes_quad(sb, s), m)
+    sb.instance(sb.sphere((0, 0, 0), float(0.7 * s)), m, Transform.translater((float(1.5 * s), float(0.5 * s), 0.0)))
+    sb.instance(sb.mesh(np.array([(-1, -1, 1), (1, -1, 1), (-1, 1, 1.5), (1, 1, 1.5), (0, 2, 1.2)]) * s, [(0, 0, -1)] * 5,
+                        [(0, 0), (1, 0), (0, 1), (1, 1), (0.5, 0.5)], [(0, 1, 2), (2, 1, 3), (2, 3, 4), (0, 2, 4), (1, 3, 4)]), m,
+                Transform().rotate_z(deg(20)).translate((float(-1.5 * s), 0.0, 0.0)))
+    sb.set_camera(64, 48, deg(60.0), (0.2 * s, 0.4 * s, -6 * s), (0, 0, 0))
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    o, d = osc.camera_rays(0, 1, 1, 9)
+    rs = np.random.RandomState(2)
+    d = (d * s * np.exp(rs.uniform(-3, 3, (len(d), 1)))).astype(np.float32)  # |d| ~ scene scale, so t = O(1) passes truncated_t
+    k = len(d) // 8
+    d[np.arange(k), rs.randint(0, 3, k)] = 0.0            # one zero component per ray
+    d[k:2 * k] *= np.float32(1e-30)                       # tiny directions
+    o[2 * k:3 * k, 1] = np.float32(1e-35)                 # tiny but non-zero origin component
+    tmax = np.where(rs.rand(len(d)) < 0.5, np.inf, 6 * np.exp(rs.uniform(-2, 2, len(d)))).astype(np.float32)
+    h_ref, occ_ref, st = osc.intersect(o, d, tmax)
+    h_gpu, occ_gpu = gpu_ctx.intersect(o, d, tmax)
+    keep = ~st["tie_mask"]
+    assert_hits_equal(h_ref[keep], h_gpu[keep])
+    assert (occ_ref == occ_gpu).all()
+    assert (h_ref["inst"] != 0xFFFFFFFF).sum() > 100
+
+
+def scenes_quad(sb, s):
+    from pbrs_amd import scenes
+    return scenes.quad_mesh(sb, (-3 * s, -1.2 * s, -3 * s), (3 * s, -1.2 * s, -3 * s), (-3 * s, -1.2 * s, 3 * s), (3 * s, -1.2 * s, 3 * s), (0, 1, 0))

@@ -77,3 +77,51 @@ def test_rejects_inconsistent_specs():
     sb.set_camera(8, 8, deg(40.0), (0, 0, -5), (0, 0, 0))
     with pytest.raises(pbrs_amd.PbrsError, match="empty instances"):
         pbrs_amd.HostScene(sb)
+
+
+def _instances(hs):
+    n = hs.desc.n_instances
+    return np.ctypeslib.as_array(C.cast(hs.desc.instances, C.POINTER(C.c_uint32)), shape=(n, 32)).copy()
+
+
+def _meshes(hs):
+    n = hs.desc.n_meshes
+    return np.ctypeslib.as_array(C.cast(hs.desc.meshes, C.POINTER(C.c_uint32)), shape=(n, 8)).copy()
+
+
+def test_precomputed_triangle_normals_and_flags():
+    """tri_verts carries `(p0-p1).cross(p2-p1).try_hat()` (simple.rs:436); flat-shaded meshes whose triangles pass the
+    tangent check of blas.rs:193-200 are flagged; identity instances are flagged; TLAS leaves carry the shape kind."""
+    from pbrs_amd import scenes
+    sb, _ = scenes.build_config("c2", width=16, height=16)
+    hs = pbrs_amd.HostScene(sb)
+    tv = np.ctypeslib.as_array(C.cast(hs.desc.tri_verts, C.POINTER(C.c_float)), shape=(hs.desc.n_triangles, 12)).copy()
+    p0, p1, p2, n = tv[:, 0:3], tv[:, 4:7], tv[:, 8:11], tv[:, [3, 7, 11]]
+    c = np.cross((p0 - p1).astype(np.float64), (p2 - p1).astype(np.float64))
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    assert np.abs(n - c).max() < 1e-6
+    meshes, inst = _meshes(hs), _instances(hs)
+    assert (meshes[:, 5] & 1).all(), "every Cornell mesh is flat shaded and passes the Q22 check"
+    is_mesh = inst[:, 24] == 5
+    identity = (inst[:, 27] & 1) != 0
+    assert identity.sum() == 8 and (~identity & is_mesh).sum() == 2  # 6 walls + 2 light triangles; the two rotated boxes are not
+    assert (inst[is_mesh, 28] == meshes[inst[is_mesh, 25], 0]).all() and (inst[is_mesh, 29] == meshes[inst[is_mesh, 25], 5]).all()
+    _, a, b = node_arrays(hs, "tlas")
+    leaf = (b & LEAF) != 0
+    assert (((b[leaf] >> 8) & 7) == inst[a[leaf], 24]).all()
+    # smooth normals (terrain): no flat-shading shortcut
+    sb, _ = scenes.build_config("c4", width=16, height=16, nx=8, nz=8)
+    hs = pbrs_amd.HostScene(sb)
+    assert (_meshes(hs)[0, 5] & 1) == 0
+
+
+def test_degenerate_triangle_gets_nan_normal():
+    from pbrs_amd.spec import SceneBuilder, deg
+    sb = SceneBuilder()
+    m = sb.lambertian((0.5, 0.5, 0.5))
+    sb.instance(sb.mesh([(0, 0, 0), (1, 0, 0), (2, 0, 0), (0, 1, 0)], [(0, 0, 1)] * 4, [(0, 0), (1, 0), (0, 1), (1, 1)], [(0, 1, 2), (0, 1, 3)]), m)
+    sb.set_camera(8, 8, deg(40.0), (0, 0, -5), (0, 0, 0))
+    hs = pbrs_amd.HostScene(sb)
+    tv = np.ctypeslib.as_array(C.cast(hs.desc.tri_verts, C.POINTER(C.c_float)), shape=(2, 12))
+    nans = np.isnan(tv[:, 3])
+    assert nans.sum() == 1  # the collinear triangle: try_hat() is None
