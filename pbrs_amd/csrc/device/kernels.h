@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const 
                                                uint32_t* next, GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t n = queue ? *count : n_direct;
-    LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
+    LaneStack stk{lds_stack + threadIdx.x};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const 
                                                GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t n = count[1];  // high half of the packed (nee paths, shadow rays) counter
-    LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
+    LaneStack stk{lds_stack + threadIdx.x};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     f3 o = ld3(origins + 3 * i), d = ld3(dirs + 3 * i);
-    LaneStack stk{lds_stack + threadIdx.x, blockDim.x};
+    LaneStack stk{lds_stack + threadIdx.x};
     Cnt<false> cnt;
     if (hits) {
         Hit h;

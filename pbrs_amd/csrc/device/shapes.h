@@ -359,12 +359,14 @@ PD bool mesh_tri_pred(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max) {
     return (s0 && s1 && s2) || (!s0 && !s1 && !s2);
 }
 
-// A per-lane stack in LDS: entry `level` of lane `lane` at stk[level * stride + lane].
+// A per-lane stack in LDS: entry `level` of a lane at base[level * 256] (lane-major rows of the 256-thread block:
+// a wave's 64 accesses to one level hit 64 consecutive dwords — no bank conflicts; the constant stride folds the
+// index arithmetic into the ds_read/ds_write address).
+#define PBRS_TRAVERSAL_BLOCK 256
 struct LaneStack {
-    uint32_t* base;  // &lds[lane]
-    uint32_t stride; // threads per block
-    PD void put(int level, uint32_t v) { base[level * stride] = v; }
-    PD uint32_t get(int level) const { return base[level * stride]; }
+    uint32_t* base;  // &lds[threadIdx.x]
+    PD void put(int level, uint32_t v) { base[level * PBRS_TRAVERSAL_BLOCK] = v; }
+    PD uint32_t get(int level) const { return base[level * PBRS_TRAVERSAL_BLOCK]; }
 };
 
 // Rebuilds the reference's world-space Interaction for the winning primitive: the object-space

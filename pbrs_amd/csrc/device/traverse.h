@@ -146,17 +146,16 @@ struct ClosestWalk {
                 else CNT(tlas_nodes);
             }
             if (!slab_rs(node, C, in_blas ? lt : t_max)) continue;
-            if (in_blas) {
-                if (node.b & PBRS_LEAF_FLAG) return true;
-                uint32_t axis = node.b & 3u;
+            if (!(node.b & PBRS_LEAF_FLAG)) {
+                // TLAS: left (i+1) is popped first.  BLAS: the child the ray enters first along the split axis
+                // (blas.rs:456-466), and the cloned ray's t_max follows outer_hit (blas.rs:468).
+                bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
                 uint32_t left = ni + 1, right = node.a;
-                bool left_first = comp(C.d, (int)axis) > 0.0f;
                 stk.put(sp++, left_first ? right : left);
                 stk.put(sp++, left_first ? left : right);
-                lt = mt;
-            } else if (!(node.b & PBRS_LEAF_FLAG)) {
-                stk.put(sp++, node.a);
-                stk.put(sp++, ni + 1);
+                lt = in_blas ? mt : lt;
+            } else if (in_blas) {
+                return true;
             } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
                 // Instance::intersect of a mesh (instance.rs:50-53): enter its BLAS without leaving the node loop
                 const pbrs_instance& in = S.inst[node.a];
@@ -297,16 +296,13 @@ struct AnyWalk {
                 else CNT(tlas_nodes);
             }
             if (!slab_rs(node, C, t_max)) continue;
-            if (in_blas) {
-                if (node.b & PBRS_LEAF_FLAG) return true;
-                uint32_t axis = node.b & 3u;
+            if (!(node.b & PBRS_LEAF_FLAG)) {
+                bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
                 uint32_t left = ni + 1, right = node.a;
-                bool left_first = comp(C.d, (int)axis) > 0.0f;
                 stk.put(sp++, left_first ? right : left);
                 stk.put(sp++, left_first ? left : right);
-            } else if (!(node.b & PBRS_LEAF_FLAG)) {
-                stk.put(sp++, node.a);
-                stk.put(sp++, ni + 1);
+            } else if (in_blas) {
+                return true;
             } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
                 const pbrs_instance& in = S.inst[node.a];
                 CNT(instances);

@@ -124,18 +124,21 @@ def test_box_test_fallback_ranges(gpu_ctx, scale):
     gpu_ctx.upload(pbrs_amd.HostScene(sb))
     o, d = osc.camera_rays(0, 1, 1, 9)
     rs = np.random.RandomState(2)
-    d = (d * s * np.exp(rs.uniform(-3, 3, (len(d), 1)))).astype(np.float32)  # |d| ~ scene scale, so t = O(1) passes truncated_t
+    # small scenes get |d| ~ scene scale so that t = O(1) passes truncated_t's EPSILON; large scenes keep |d| ~ 1
+    # (|d| ~ 1e13 overflows the triangle determinant and the sphere discriminant in f32: no hits at all)
+    ds = np.float32(min(scale, 1.0))
+    d = (d * ds * np.exp(rs.uniform(-3, 3, (len(d), 1)))).astype(np.float32)
     k = len(d) // 8
     d[np.arange(k), rs.randint(0, 3, k)] = 0.0            # one zero component per ray
     d[k:2 * k] *= np.float32(1e-30)                       # tiny directions
     o[2 * k:3 * k, 1] = np.float32(1e-35)                 # tiny but non-zero origin component
-    tmax = np.where(rs.rand(len(d)) < 0.5, np.inf, 6 * np.exp(rs.uniform(-2, 2, len(d)))).astype(np.float32)
+    tmax = np.where(rs.rand(len(d)) < 0.5, np.inf, 6 * (s / ds) * np.exp(rs.uniform(-2, 2, len(d)))).astype(np.float32)
     h_ref, occ_ref, st = osc.intersect(o, d, tmax)
     h_gpu, occ_gpu = gpu_ctx.intersect(o, d, tmax)
     keep = ~st["tie_mask"]
     assert_hits_equal(h_ref[keep], h_gpu[keep])
     assert (occ_ref == occ_gpu).all()
-    assert (h_ref["inst"] != 0xFFFFFFFF).sum() > 100
+    assert (h_ref["inst"] != 0xFFFFFFFF).sum() > 50
 
 
 def scenes_quad(sb, s):
