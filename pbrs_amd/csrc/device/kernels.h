@@ -176,27 +176,13 @@ __global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const 
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
     ClosestWalk<STATS> walk;
+    walk.mode = PBRS_WALK_IDLE;
     uint32_t slot = 0;
-    bool active = false;
     WaveWork work = wave_work_init(n);
     for (;;) {
-        uint64_t am = __ballot(active);
-        if (!(work.exhausted && work.cur >= work.end) && __popcll(am) < PBRS_REFILL_BELOW) {
-            uint32_t idx = wave_fetch(work, !active, next, n);
-            if (idx != 0xffffffffu) {
-                slot = queue ? queue[idx] : idx;
-                f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
-                walk.start(S, o, d, pn_inf(), stk);
-                active = true;
-                nrays++;
-            }
-            am = __ballot(active);
-        }
-        if (am == 0) break;
-        if (active) {
-            if (walk.node_phase(S, stk, cnt)) {
-                walk.leaf_phase(S, cnt);
-            } else {
+        uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
+        if (__popcll(live) < PBRS_REFILL_BELOW) {
+            if (walk.mode == PBRS_WALK_DONE) {  // finished walks are retired in batches, at refill time
                 const Hit& h = walk.best;
                 nhit += h.inst != 0xffffffffu ? 1u : 0u;
                 st.ht[slot] = h.t;
@@ -204,9 +190,22 @@ __global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const 
                 st.hprim[slot] = h.prim;
                 st.hb1[slot] = h.b1;
                 st.hb2[slot] = h.b2;
-                active = false;
+                walk.mode = PBRS_WALK_IDLE;
             }
+            if (!(work.exhausted && work.cur >= work.end)) {
+                uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
+                if (idx != 0xffffffffu) {
+                    slot = queue ? queue[idx] : idx;
+                    f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
+                    walk.start(S, o, d, pn_inf(), stk);
+                    nrays++;
+                }
+                live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
+            }
+            if (live == 0) break;
         }
+        if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);
+        if (walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt);
     }
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
 }
@@ -441,34 +440,14 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const 
     cnt.init();
     uint32_t nrays = 0;
     AnyWalk<STATS> walk;
+    walk.mode = PBRS_WALK_IDLE;
     uint32_t item = 0;
-    bool active = false;
     WaveWork work = wave_work_init(n);
     for (;;) {
-        uint64_t am = __ballot(active);
-        if (!(work.exhausted && work.cur >= work.end) && __popcll(am) < PBRS_REFILL_BELOW) {
-            uint32_t idx = wave_fetch(work, !active, next, n);
-            if (idx != 0xffffffffu) {
-                item = queue[idx];
-                uint32_t slot = item & 0x3fffffffu, r = item >> 31;
-                f3 o = mk3(st.so[r][0][slot], st.so[r][1][slot], st.so[r][2][slot]);
-                f3 d = mk3(st.sd[r][0][slot], st.sd[r][1][slot], st.sd[r][2][slot]);
-                walk.start(S, o, d, st.stmax[r][slot], stk);
-                active = true;
-                nrays++;
-            }
-            am = __ballot(active);
-        }
-        if (am == 0) break;
-        if (active) {
-            bool done = false, occluded = false;
-            if (walk.node_phase(S, stk, cnt)) {
-                occluded = walk.leaf_phase(S, cnt);
-                done = occluded;
-            } else {
-                done = true;
-            }
-            if (done) {
+        uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
+        if (__popcll(live) < PBRS_REFILL_BELOW) {
+            if (walk.mode == PBRS_WALK_DONE) {
+                const bool occluded = walk.occluded;
                 const uint32_t slot = item & 0x3fffffffu, r = item >> 31;
                 if (item & 0x40000000u) {
                     // the path's only shadow ray: nothing to wait for, finish the estimate here
@@ -491,9 +470,24 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const 
                 } else {
                     st.occ[r][slot] = occluded ? 1 : 0;
                 }
-                active = false;
+                walk.mode = PBRS_WALK_IDLE;
             }
+            if (!(work.exhausted && work.cur >= work.end)) {
+                uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
+                if (idx != 0xffffffffu) {
+                    item = queue[idx];
+                    uint32_t slot = item & 0x3fffffffu, r = item >> 31;
+                    f3 o = mk3(st.so[r][0][slot], st.so[r][1][slot], st.so[r][2][slot]);
+                    f3 d = mk3(st.sd[r][0][slot], st.sd[r][1][slot], st.sd[r][2][slot]);
+                    walk.start(S, o, d, st.stmax[r][slot], stk);
+                    nrays++;
+                }
+                live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
+            }
+            if (live == 0) break;
         }
+        if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);
+        if (walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt);
     }
     flush_counters<STATS>(cnt, gc, true, nrays, 0u);
 }

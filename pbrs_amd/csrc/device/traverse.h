@@ -89,16 +89,24 @@ PD RaySpace enter_instance(const DevScene& S, const pbrs_instance& in, const Ray
 //  * the mesh may return a hit beyond the incoming extent (it loses at the TLAS compare).
 // Known deviation: ray.t_max is never RAISED by such an overshoot; observable only on
 // bit-identical t from two instances (oracle counter tlas_ties).
+// Walk states.  A kernel advances every lane by single steps — one node (pop + box test) or one primitive — so that
+// lanes of one wave that are in different phases of their walks still share the instruction stream (k_extend).
+#define PBRS_WALK_IDLE 0u
+#define PBRS_WALK_NODE 1u
+#define PBRS_WALK_LEAF 2u
+#define PBRS_WALK_DONE 3u
+
 template <bool STATS>
 struct ClosestWalk {
     RaySpace W, C;  // world ray; C = the space the lane is walking in (W in the TLAS, the instance's ray in a BLAS).
                     // One box-test call on C serves lanes in either tree: no branch duplicates the test.
-    Hit best;
+    Hit best;       // best.t stays +inf until the first candidate: `!(best.t < t)` then accepts it, as Option::None does
     float t_max, lt, mt, mb1, mb2;  // lt: the cloned ray's t_max inside intersect_bvh; mt: outer_hit.ray_t
-    uint32_t mprim, cur_inst, mesh_flags, ni;
+    uint32_t mprim, cur_inst, mesh_flags;
+    uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or leaf_a = the TLAS leaf's instance
     int sp, blas_base;
-    bool have, in_blas;
-    pbrs_node node;  // the leaf held between node_phase and leaf_phase
+    bool in_blas;
+    uint32_t mode;
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         W = make_space(o, d, S.fast_slab != 0);
@@ -107,102 +115,108 @@ struct ClosestWalk {
         best.inst = 0xffffffffu;
         best.prim = 0;
         best.b1 = best.b2 = 0.0f;
-        have = false;
         in_blas = false;
         t_max = tmax;
         lt = 0.0f;
         mt = pn_inf();
-        mprim = cur_inst = mesh_flags = ni = 0;
+        mprim = cur_inst = mesh_flags = leaf_a = leaf_end = 0;
         mb1 = mb2 = 0.0f;
         blas_base = 0;
         stk.put(0, 0u);
         sp = 1;
+        mode = PBRS_WALK_NODE;
     }
 
-    // Pops and box-tests nodes until the lane holds primitives to test (returns true) or the walk is over (false).
-    PD bool node_phase(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
-        for (;;) {
-            if (in_blas && sp == blas_base) {  // intersect_bvh returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
-                in_blas = false;
-                C = W;
-                if (mt < pn_inf()) {
-                    CNT(instance_hits);
-                    if (!have || !(best.t < mt)) {
-                        have = true;
-                        best.t = mt;
-                        best.inst = cur_inst;
-                        best.prim = mprim;
-                        best.b1 = mb1;
-                        best.b2 = mb2;
-                        t_max = mt;
-                    }
+    // One node: pop, box test, then push the children / hold the leaf / enter the mesh instance.
+    PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        if (in_blas && sp == blas_base) {  // intersect_bvh returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
+            in_blas = false;
+            C = W;
+            if (mt < pn_inf()) {
+                CNT(instance_hits);
+                if (!(best.t < mt)) {
+                    best.t = mt;
+                    best.inst = cur_inst;
+                    best.prim = mprim;
+                    best.b1 = mb1;
+                    best.b2 = mb2;
+                    t_max = mt;
                 }
             }
-            if (sp == 0) return false;
-            ni = stk.get(--sp);
-            node = load_node((in_blas ? S.blas : S.tlas) + ni);
-            if (STATS) {
-                if (in_blas) CNT(blas_nodes);
-                else CNT(tlas_nodes);
-            }
-            if (!slab_rs(node, C, in_blas ? lt : t_max)) continue;
-            if (!(node.b & PBRS_LEAF_FLAG)) {
-                // TLAS: left (i+1) is popped first.  BLAS: the child the ray enters first along the split axis
-                // (blas.rs:456-466), and the cloned ray's t_max follows outer_hit (blas.rs:468).
-                bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
-                uint32_t left = ni + 1, right = node.a;
-                stk.put(sp++, left_first ? right : left);
-                stk.put(sp++, left_first ? left : right);
-                lt = in_blas ? mt : lt;
-            } else if (in_blas) {
-                return true;
-            } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
-                // Instance::intersect of a mesh (instance.rs:50-53): enter its BLAS without leaving the node loop
-                const pbrs_instance& in = S.inst[node.a];
-                CNT(instances);
-                C = enter_instance(S, in, W);
-                in_blas = true;
-                blas_base = sp;
-                cur_inst = node.a;
-                mesh_flags = in.mesh_flags;
-                lt = t_max;
-                mt = pn_inf();
-                stk.put(sp++, in.blas_root);
-            } else {
-                return true;
-            }
+        }
+        if (sp == 0) {
+            mode = PBRS_WALK_DONE;
+            return;
+        }
+        const uint32_t ni = stk.get(--sp);
+        const pbrs_node node = load_node((in_blas ? S.blas : S.tlas) + ni);
+        if (STATS) {
+            if (in_blas) CNT(blas_nodes);
+            else CNT(tlas_nodes);
+        }
+        if (!slab_rs(node, C, in_blas ? lt : t_max)) return;
+        if (!(node.b & PBRS_LEAF_FLAG)) {
+            // TLAS: left (i+1) is popped first.  BLAS: the child the ray enters first along the split axis
+            // (blas.rs:456-466), and the cloned ray's t_max follows outer_hit (blas.rs:468).
+            bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
+            uint32_t left = ni + 1, right = node.a;
+            stk.put(sp++, left_first ? right : left);
+            stk.put(sp++, left_first ? left : right);
+            lt = in_blas ? mt : lt;
+        } else if (in_blas) {
+            leaf_a = node.a;
+            leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
+            if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
+            else lt = mt;  // an empty leaf still runs blas.rs:468
+        } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
+            // Instance::intersect of a mesh (instance.rs:50-53): enter its BLAS without leaving the node state
+            const pbrs_instance& in = S.inst[node.a];
+            CNT(instances);
+            C = enter_instance(S, in, W);
+            in_blas = true;
+            blas_base = sp;
+            cur_inst = node.a;
+            mesh_flags = in.mesh_flags;
+            lt = t_max;
+            mt = pn_inf();
+            stk.put(sp++, in.blas_root);
+        } else {
+            leaf_a = node.a;
+            mode = PBRS_WALK_LEAF;
         }
     }
 
-    // Tests the primitives of the held leaf: the triangles of a BLAS leaf, or the analytic shape of a TLAS leaf.
-    PD void leaf_phase(const DevScene& S, Cnt<STATS>& cnt) {
+    // One primitive of the held leaf: the next triangle of a BLAS leaf, or the analytic shape of a TLAS leaf.
+    PD void leaf_step(const DevScene& S, Cnt<STATS>& cnt) {
         if (in_blas) {
-            uint32_t count = node.b & ~PBRS_LEAF_FLAG;
-            for (uint32_t k = 0; k < count; ++k) {
-                uint32_t ti = node.a + k;
-                pbrs_tri_verts tv = load_tri(S.tv + ti);
-                CNT(triangles);
-                TriHit h;
-                if (!mesh_tri_hit(tv, C.o, C.d, lt, h)) continue;
-                CNT(tri_shading);
-                // The reference builds the shading frame of every geometric hit (blas.rs:166-206) and drops the
-                // hit when the tangent check fails (Q22).  Only a hit that would replace outer_hit can change the
-                // result, and for a flat-shaded mesh the check is a host-verified property of the triangles.
-                if (!(h.t < mt)) continue;
-                if (!(mesh_flags & PBRS_MESH_FLAT_SHADING_OK)) {
-                    f3 n, dpdu;
-                    if (!mesh_tri_shading(tv, S.ts[ti], C.d, h, n, dpdu)) continue;
-                }
+            const uint32_t ti = leaf_a++;
+            if (leaf_a == leaf_end) mode = PBRS_WALK_NODE;
+            pbrs_tri_verts tv = load_tri(S.tv + ti);
+            CNT(triangles);
+            TriHit h;
+            bool hit = mesh_tri_hit(tv, C.o, C.d, lt, h);
+            if (hit) CNT(tri_shading);
+            // The reference builds the shading frame of every geometric hit (blas.rs:166-206) and drops the
+            // hit when the tangent check fails (Q22).  Only a hit that would replace outer_hit can change the
+            // result, and for a flat-shaded mesh the check is a host-verified property of the triangles.
+            hit = hit && h.t < mt;
+            if (hit && !(mesh_flags & PBRS_MESH_FLAT_SHADING_OK)) {
+                f3 n, dpdu;
+                hit = mesh_tri_shading(tv, S.ts[ti], C.d, h, n, dpdu);
+            }
+            if (hit) {
                 mt = h.t;
                 mprim = ti;
                 mb1 = h.b1;
                 mb2 = h.b2;
             }
-            lt = mt;
+            // within a leaf every triangle sees the t_max from before the leaf (blas.rs:440-452)
+            if (mode == PBRS_WALK_NODE) lt = mt;
             return;
         }
+        mode = PBRS_WALK_NODE;
         // Instance::intersect of an analytic shape (instance.rs:50-67)
-        const pbrs_instance& in = S.inst[node.a];
+        const pbrs_instance& in = S.inst[leaf_a];
         CNT(instances);
         f3 oo = xf_apply(in.inv, W.o, 1.0f);
         f3 od = xf_apply(in.inv, W.d, 0.0f);
@@ -246,10 +260,9 @@ struct ClosestWalk {
         }
         if (!hit) return;
         CNT(instance_hits);
-        if (!have || !(best.t < t)) {
-            have = true;
+        if (!(best.t < t)) {
             best.t = t;
-            best.inst = node.a;
+            best.inst = leaf_a;
             best.prim = 0;
             best.b1 = b1;
             best.b2 = b2;
@@ -267,86 +280,102 @@ template <bool STATS>
 struct AnyWalk {
     RaySpace W, C;
     float t_max;
-    uint32_t ni;
+    uint32_t leaf_a, leaf_end;
     int sp, blas_base;
-    bool in_blas;
-    pbrs_node node;
+    bool in_blas, occluded;
+    uint32_t mode;
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         W = make_space(o, d, S.fast_slab != 0);
         C = W;
         t_max = tmax;
         in_blas = false;
+        occluded = false;
         blas_base = 0;
-        ni = 0;
+        leaf_a = leaf_end = 0;
         stk.put(0, 0u);
         sp = 1;
+        mode = PBRS_WALK_NODE;
     }
-    PD bool node_phase(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
-        for (;;) {
-            if (in_blas && sp == blas_base) {
-                in_blas = false;
-                C = W;
-            }
-            if (sp == 0) return false;
-            ni = stk.get(--sp);
-            node = load_node((in_blas ? S.blas : S.tlas) + ni);
-            if (STATS) {
-                if (in_blas) CNT(blas_nodes);
-                else CNT(tlas_nodes);
-            }
-            if (!slab_rs(node, C, t_max)) continue;
-            if (!(node.b & PBRS_LEAF_FLAG)) {
-                bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
-                uint32_t left = ni + 1, right = node.a;
-                stk.put(sp++, left_first ? right : left);
-                stk.put(sp++, left_first ? left : right);
-            } else if (in_blas) {
-                return true;
-            } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
-                const pbrs_instance& in = S.inst[node.a];
-                CNT(instances);
-                C = enter_instance(S, in, W);
-                in_blas = true;
-                blas_base = sp;
-                stk.put(sp++, in.blas_root);
-            } else {
-                return true;
-            }
+    PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        if (in_blas && sp == blas_base) {
+            in_blas = false;
+            C = W;
+        }
+        if (sp == 0) {
+            mode = PBRS_WALK_DONE;
+            return;
+        }
+        const uint32_t ni = stk.get(--sp);
+        const pbrs_node node = load_node((in_blas ? S.blas : S.tlas) + ni);
+        if (STATS) {
+            if (in_blas) CNT(blas_nodes);
+            else CNT(tlas_nodes);
+        }
+        if (!slab_rs(node, C, t_max)) return;
+        if (!(node.b & PBRS_LEAF_FLAG)) {
+            bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
+            uint32_t left = ni + 1, right = node.a;
+            stk.put(sp++, left_first ? right : left);
+            stk.put(sp++, left_first ? left : right);
+        } else if (in_blas) {
+            leaf_a = node.a;
+            leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
+            if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
+        } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
+            const pbrs_instance& in = S.inst[node.a];
+            CNT(instances);
+            C = enter_instance(S, in, W);
+            in_blas = true;
+            blas_base = sp;
+            stk.put(sp++, in.blas_root);
+        } else {
+            leaf_a = node.a;
+            mode = PBRS_WALK_LEAF;
         }
     }
-    // true = occluded
-    PD bool leaf_phase(const DevScene& S, Cnt<STATS>& cnt) {
+    // One primitive; an occluder ends the walk (mode DONE, occluded set).
+    PD void leaf_step(const DevScene& S, Cnt<STATS>& cnt) {
+        bool hit;
         if (in_blas) {
-            uint32_t count = node.b & ~PBRS_LEAF_FLAG;
-            for (uint32_t k = 0; k < count; ++k) {
-                pbrs_tri_verts tv = load_tri(S.tv + node.a + k);
-                CNT(triangles);
-                if (mesh_tri_pred(tv, C.o, C.d, t_max)) return true;
+            const uint32_t ti = leaf_a++;
+            pbrs_tri_verts tv = load_tri(S.tv + ti);
+            CNT(triangles);
+            hit = mesh_tri_pred(tv, C.o, C.d, t_max);
+            mode = leaf_a == leaf_end ? PBRS_WALK_NODE : PBRS_WALK_LEAF;
+        } else {
+            const pbrs_instance& in = S.inst[leaf_a];
+            CNT(instances);
+            f3 oo = xf_apply(in.inv, W.o, 1.0f);
+            f3 od = xf_apply(in.inv, W.d, 0.0f);
+            const float* p = S.shapes[in.shape_index].p;
+            switch (in.shape_kind) {
+                case PBRS_SHAPE_SPHERE:
+                    CNT(spheres);
+                    hit = sphere_occludes(ld3(p), p[3], oo, od, t_max);
+                    break;
+                case PBRS_SHAPE_QUAD:
+                    CNT(quads);
+                    hit = quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
+                    break;
+                case PBRS_SHAPE_CUBOID:  // Q14: the bbox slab test
+                    CNT(cuboids);
+                    hit = slab_test(ld3(p), ld3(p + 3), oo, od, t_max);
+                    break;
+                case PBRS_SHAPE_DISK:
+                    CNT(disks);
+                    hit = disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od);
+                    break;
+                default:
+                    CNT(triangles);
+                    hit = tri_pred(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
+                    break;
             }
-            return false;
+            mode = PBRS_WALK_NODE;
         }
-        const pbrs_instance& in = S.inst[node.a];
-        CNT(instances);
-        f3 oo = xf_apply(in.inv, W.o, 1.0f);
-        f3 od = xf_apply(in.inv, W.d, 0.0f);
-        const float* p = S.shapes[in.shape_index].p;
-        switch (in.shape_kind) {
-            case PBRS_SHAPE_SPHERE:
-                CNT(spheres);
-                return sphere_occludes(ld3(p), p[3], oo, od, t_max);
-            case PBRS_SHAPE_QUAD:
-                CNT(quads);
-                return quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
-            case PBRS_SHAPE_CUBOID:  // Q14: the bbox slab test
-                CNT(cuboids);
-                return slab_test(ld3(p), ld3(p + 3), oo, od, t_max);
-            case PBRS_SHAPE_DISK:
-                CNT(disks);
-                return disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od);
-            default:
-                CNT(triangles);
-                return tri_pred(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
+        if (hit) {
+            occluded = true;
+            mode = PBRS_WALK_DONE;
         }
     }
 };
@@ -356,14 +385,19 @@ template <bool STATS>
 PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
     ClosestWalk<STATS> w;
     w.start(S, o, d, t_max, stk);
-    while (w.node_phase(S, stk, cnt)) w.leaf_phase(S, cnt);
+    while (w.mode != PBRS_WALK_DONE) {
+        if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
+        if (w.mode == PBRS_WALK_LEAF) w.leaf_step(S, cnt);
+    }
     best = w.best;
 }
 template <bool STATS>
 PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
     AnyWalk<STATS> w;
     w.start(S, o, d, t_max, stk);
-    while (w.node_phase(S, stk, cnt))
-        if (w.leaf_phase(S, cnt)) return true;
-    return false;
+    while (w.mode != PBRS_WALK_DONE) {
+        if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
+        if (w.mode == PBRS_WALK_LEAF) w.leaf_step(S, cnt);
+    }
+    return w.occluded;
 }
