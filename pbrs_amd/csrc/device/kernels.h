@@ -123,25 +123,59 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #define PBRS_SHADE_WAVES 3
 #endif
 
+// One round of the traversal loop.  Lanes in the node state take a node step, then lanes holding a leaf test one
+// primitive.  A step is skipped while fewer than PBRS_NODE_MIN / PBRS_LEAF_MIN lanes want it and the other kind of
+// lane still has work (those lanes wait and the step later runs fuller); with both thresholds at 1 this is the
+// plain "if-if" loop.
+#ifndef PBRS_NODE_MIN
+#define PBRS_NODE_MIN 1
+#endif
+#ifndef PBRS_LEAF_MIN
+#define PBRS_LEAF_MIN 1
+#endif
+#define PBRS_STEP_WALK(walk, S, stk, cnt)                                                         \
+    do {                                                                                          \
+        if (PBRS_NODE_MIN > 1 || PBRS_LEAF_MIN > 1) {                                             \
+            const uint32_t nn = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_NODE));        \
+            const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));        \
+            const bool do_node = nn >= PBRS_NODE_MIN || nl < PBRS_LEAF_MIN;                       \
+            if (do_node && walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);              \
+            const uint32_t nl2 = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));       \
+            if ((nl2 >= PBRS_LEAF_MIN || !do_node || nn == 0) && walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt); \
+        } else {                                                                                  \
+            if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                         \
+            if (walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt);                              \
+        }                                                                                         \
+    } while (0)
+
 // Work fetch of the persistent traversal kernels.  A wave owns a private range [cur, end) of queue items and hands
 // them to its idle lanes without touching memory; only when the range is empty does its first idle lane take a new
-// chunk from the device-wide head with one atomicAdd (a hot head word serialises at ~10 ns per atomic, so per-refill
-// atomics would throttle the kernel).  All values are wave-uniform.
+// chunk with one atomicAdd.  A single device-wide head word serialises at ~10 ns per atomic, which capped the kernels
+// at chunk / 10 ns items per second, so the queue is cut into PBRS_WORK_HEADS contiguous segments, each with its own
+// head word on its own 128-byte line.  A block starts on segment blockIdx.x % 8 — blocks are dealt round-robin to
+// the 8 XCDs, so neighbouring rays stay within one XCD's L2 — and moves on to the next segment when its own is empty.
+// All values are wave-uniform.
+#define PBRS_WORK_HEADS 8u
+#define PBRS_WORK_HEAD_STRIDE 32u  // u32 words between head words
 struct WaveWork {
     uint32_t cur, end, chunk;
-    bool exhausted;
+    uint32_t head, tried;  // segment in use; segments found empty so far
+    PD bool left() const { return tried < PBRS_WORK_HEADS || cur < end; }
 };
 PD WaveWork wave_work_init(uint32_t n) {
     // small queues (late bounces) get small chunks so that every wave still finds work
     uint32_t waves = gridDim.x * (blockDim.x >> 6);
     uint32_t chunk = n / (waves * 4u);
     chunk = chunk < 64u ? 64u : (chunk > PBRS_CHUNK_MAX ? PBRS_CHUNK_MAX : (chunk & ~63u));
-    return WaveWork{0u, 0u, chunk, false};
+    return WaveWork{0u, 0u, chunk, blockIdx.x % PBRS_WORK_HEADS, 0u};
+}
+PD uint32_t work_segment(uint32_t n, uint32_t h) {
+    return h >= PBRS_WORK_HEADS ? n : (uint32_t)(((unsigned long long)n * h / PBRS_WORK_HEADS) & ~63ull);
 }
 // Lanes with `need` get an item index < n (returned; 0xffffffff = none).  Items left in the wave's range are handed
 // out first; if they do not cover every idle lane a new chunk is taken in the same call, so a refill never leaves
 // lanes idle while the queue still holds work.
-PD uint32_t wave_fetch(WaveWork& w, bool need, uint32_t* head, uint32_t n) {
+PD uint32_t wave_fetch(WaveWork& w, bool need, uint32_t* heads, uint32_t n) {
     const uint64_t mask = __ballot(need);
     const uint32_t want = (uint32_t)__popcll(mask), rank = lane_prefix(mask);
     const uint32_t avail = w.end - w.cur;
@@ -151,17 +185,25 @@ PD uint32_t wave_fetch(WaveWork& w, bool need, uint32_t* head, uint32_t n) {
         return idx;
     }
     w.cur = w.end;
-    if (w.exhausted) return idx;
-    int leader = __ffsll((unsigned long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(head, w.chunk);
-    base = __shfl(base, leader, 64);
-    const uint32_t lo = base < n ? base : n, hi = base + w.chunk < n ? base + w.chunk : n;
-    if (base + w.chunk >= n) w.exhausted = true;  // nothing beyond this chunk
-    const uint32_t rest = want - avail, got = hi - lo;
-    if (need && rank >= avail && lo + (rank - avail) < hi) idx = lo + (rank - avail);
-    w.cur = lo + (rest < got ? rest : got);
-    w.end = hi;
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    while (w.tried < PBRS_WORK_HEADS) {  // ends: every pass either returns or retires one segment
+        const uint32_t seg_lo = work_segment(n, w.head), seg_hi = work_segment(n, w.head + 1);
+        uint32_t base = 0;
+        if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(heads + w.head * PBRS_WORK_HEAD_STRIDE, w.chunk);
+        base = __shfl(base, leader, 64);
+        const uint32_t len = seg_hi - seg_lo;
+        const uint32_t lo = seg_lo + (base < len ? base : len), hi = seg_lo + (base + w.chunk < len ? base + w.chunk : len);
+        if (base + w.chunk >= len) {  // nothing beyond this chunk in the segment
+            w.head = (w.head + 1u) % PBRS_WORK_HEADS;
+            w.tried++;
+        }
+        if (lo == hi) continue;
+        const uint32_t rest = want - avail, got = hi - lo;
+        if (need && rank >= avail && rank - avail < got) idx = lo + (rank - avail);
+        w.cur = lo + (rest < got ? rest : got);
+        w.end = hi;
+        break;
+    }
     return idx;
 }
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
@@ -192,7 +234,7 @@ __global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const 
                 st.hb2[slot] = h.b2;
                 walk.mode = PBRS_WALK_IDLE;
             }
-            if (!(work.exhausted && work.cur >= work.end)) {
+            if (work.left()) {
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
                     slot = queue ? queue[idx] : idx;
@@ -204,8 +246,7 @@ __global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const 
             }
             if (live == 0) break;
         }
-        if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);
-        if (walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt);
+        PBRS_STEP_WALK(walk, S, stk, cnt);
     }
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
 }
@@ -472,7 +513,7 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const 
                 }
                 walk.mode = PBRS_WALK_IDLE;
             }
-            if (!(work.exhausted && work.cur >= work.end)) {
+            if (work.left()) {
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
                     item = queue[idx];
@@ -486,8 +527,7 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const 
             }
             if (live == 0) break;
         }
-        if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);
-        if (walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt);
+        PBRS_STEP_WALK(walk, S, stk, cnt);
     }
     flush_counters<STATS>(cnt, gc, true, nrays, 0u);
 }

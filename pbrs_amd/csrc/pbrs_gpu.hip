@@ -20,6 +20,8 @@ namespace {
 
 constexpr uint32_t kBlock = 256;
 constexpr uint32_t kMaxDepth = 64;
+constexpr uint32_t kHeadWords = PBRS_WORK_HEADS * PBRS_WORK_HEAD_STRIDE;
+constexpr uint32_t kCounterWords = (3 + 2 * kHeadWords) * (kMaxDepth + 2);  // act, ns (u64), then the work heads
 constexpr uint32_t kPersistentBlocks = 256 * 6;  // 256 CUs x up to 6 resident 256-thread blocks (VGPR/LDS permitting)
 constexpr size_t kLdsBytesPerCU = 160 * 1024;
 
@@ -47,7 +49,7 @@ struct pbrs_ctx {
     void* state_mem = nullptr;
     PathState st{};
     uint32_t* queues = nullptr;   // 5 * cap_slots: ping, pong, nee, shadow rays (2 per path)
-    uint32_t* counters = nullptr; // 5 * (kMaxDepth + 2): act, shc, nee, extend work heads, shadow work heads
+    uint32_t* counters = nullptr; // kCounterWords: act, ns (u64), extend work heads, shadow work heads
     float* sum = nullptr;         // 3 * cap_pixels, planar
     float* rgb_dev = nullptr;     // 3 * cap_pixels, row-major (for the host-output variant)
     GlobalCounters* gcnt = nullptr;  // [0] extend, [1] shadow
@@ -239,12 +241,13 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     uint32_t* act = c->counters;                 // act[b]: paths entering bounce b (b >= 1)
     // ns[b]: one 64-bit word per bounce: low half = paths whose light estimate waits for visibility, high half = shadow rays
     unsigned long long* ns = reinterpret_cast<unsigned long long*>(c->counters + stride);
-    uint32_t* xhead = c->counters + 3 * stride;  // work-fetch heads of k_extend / k_shadow per bounce
-    uint32_t* shead = c->counters + 4 * stride;
+    // work-fetch heads of k_extend / k_shadow: kHeadWords words per bounce (one head per queue segment, kernels.h)
+    uint32_t* xhead = c->counters + 3 * stride;
+    uint32_t* shead = xhead + stride * kHeadWords;
     uint32_t* q[2] = {c->queues, c->queues + c->cap_slots};
     uint32_t* neeq = c->queues + 2 * c->cap_slots;
     uint32_t* shq = c->queues + 3 * c->cap_slots;
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, 5 * stride * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(uint32_t), c->stream));
     if (tm.begin(0)) return fail(c, PBRS_E_DEVICE, "event record failed");
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, c->st, rc);
     tm.end();
@@ -253,9 +256,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         const uint32_t* qin = b == 0 ? nullptr : q[b & 1];
         if (tm.begin(1)) return fail(c, PBRS_E_DEVICE, "event record failed");
         if (stats)
-            hipLaunchKernelGGL(k_extend<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, xhead + b, c->gcnt);
+            hipLaunchKernelGGL(k_extend<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, xhead + b * kHeadWords, c->gcnt);
         else
-            hipLaunchKernelGGL(k_extend<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, xhead + b, c->gcnt);
+            hipLaunchKernelGGL(k_extend<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, xhead + b * kHeadWords, c->gcnt);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
         hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], act + b + 1, shq,
@@ -263,9 +266,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
         if (stats)
-            hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b, c->gcnt + 1);
+            hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords, c->gcnt + 1);
         else
-            hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b, c->gcnt + 1);
+            hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords, c->gcnt + 1);
         hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
         tm.end();
     }
@@ -358,7 +361,7 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     c->stream = c->own_stream;
     c->total_ev.resize(2);
     if (hipEventCreate(&c->total_ev[0]) != hipSuccess || hipEventCreate(&c->total_ev[1]) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->counters), 5 * (kMaxDepth + 2) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) != hipSuccess) {
         delete c;
         return PBRS_E_DEVICE;
