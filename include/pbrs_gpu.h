@@ -61,7 +61,8 @@ typedef struct pbrs_instance {
     uint32_t shape_index; /* analytic: index into shapes[]; mesh: index into meshes[] */
     uint32_t material;
     uint32_t flags; /* PBRS_INSTANCE_* */
-    /* mesh instances: copies of meshes[shape_index].root / .flags so that entering the BLAS costs one record */
+    /* mesh instances: copies of meshes[shape_index].root / .flags so that entering the BLAS costs one record;
+     * PBRS_SHAPE_TRIANGLE instances: blas_root = index of the triangle's own record in tri_verts[] */
     uint32_t blas_root;
     uint32_t mesh_flags;
     uint32_t pad[2];
@@ -89,6 +90,12 @@ typedef struct pbrs_mesh {
  * shape/src/blas.rs:193-200 (which then depends on the triangle only, not on the hit or the ray), so the
  * traversal need not evaluate the shading frame of candidate hits. */
 #define PBRS_MESH_FLAT_SHADING_OK 1u
+/* Every triangle of the mesh passes the same tangent check for ANY hit on it, by a bound instead of an identity: the
+ * rejected quantity |dpdu . n| is the rounding residue of a Gram-Schmidt step and stays below 12 eps / sin(theta),
+ * theta = angle(dpdu_raw, n); the host proves sin(theta) >= 0.044 for every normal the interpolation can produce
+ * (host/flatten.cpp, `smooth_shading_bound`), i.e. |dpdu . n| < 2e-5 against the 1e-3 threshold. */
+#define PBRS_MESH_SMOOTH_SHADING_OK 2u
+#define PBRS_MESH_SHADING_OK_MASK 3u
 
 /* One triangle's geometry in BLAS leaf order, Q11 swap applied: `let (i,k,j) = index_triple`
  * (shape/src/blas.rs:162) => p0 = positions[i], p1 = positions[j], p2 = positions[k].

@@ -119,6 +119,9 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #ifndef PBRS_CHUNK_MAX
 #define PBRS_CHUNK_MAX 512u
 #endif
+#ifndef PBRS_TRAV_WAVES  // min waves per SIMD asked of the register allocator for k_extend / k_shadow
+#define PBRS_TRAV_WAVES 5
+#endif
 #ifndef PBRS_SHADE_WAVES  // min waves per SIMD asked of the register allocator for k_shade (2nd arg of __launch_bounds__)
 #define PBRS_SHADE_WAVES 3
 #endif
@@ -143,10 +146,26 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
             const uint32_t nl2 = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));       \
             if ((nl2 >= PBRS_LEAF_MIN || !do_node || nn == 0) && walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt); \
         } else {                                                                                  \
+            PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                     \
             if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                         \
             if (walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt);                              \
         }                                                                                         \
     } while (0)
+// developer probe (tools/util_probe.py, instrumented variant only): wave-level executions of the node and leaf steps,
+// stashed in the cuboid / disk counters of a scene that has neither
+#ifdef PBRS_PROBE_UTIL
+#define PBRS_PROBE_UTIL_COUNT(walk, cnt)                                                          \
+    do {                                                                                          \
+        if (STATS) {                                                                              \
+            const uint64_t pn = __ballot(walk.mode == PBRS_WALK_NODE);                            \
+            if (pn && (threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)pn) - 1)) cnt.c.cuboids++; \
+        }                                                                                         \
+    } while (0)
+#else
+#define PBRS_PROBE_UTIL_COUNT(walk, cnt) \
+    do {                                 \
+    } while (0)
+#endif
 
 // Work fetch of the persistent traversal kernels.  A wave owns a private range [cur, end) of queue items and hands
 // them to its idle lanes without touching memory; only when the range is empty does its first idle lane take a new
@@ -155,7 +174,9 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 // head word on its own 128-byte line.  A block starts on segment blockIdx.x % 8 — blocks are dealt round-robin to
 // the 8 XCDs, so neighbouring rays stay within one XCD's L2 — and moves on to the next segment when its own is empty.
 // All values are wave-uniform.
+#ifndef PBRS_WORK_HEADS
 #define PBRS_WORK_HEADS 8u
+#endif
 #define PBRS_WORK_HEAD_STRIDE 32u  // u32 words between head words
 struct WaveWork {
     uint32_t cur, end, chunk;
@@ -208,16 +229,16 @@ PD uint32_t wave_fetch(WaveWork& w, bool need, uint32_t* heads, uint32_t n) {
 }
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
 // handed a new ray at the next refill, the walks of the other lanes continue where they were.
-template <bool STATS>
-__global__ void __launch_bounds__(256) k_extend(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t n_direct,
+template <bool STATS, uint32_t FEAT>
+__global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_extend(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t n_direct,
                                                uint32_t* next, GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t n = queue ? *count : n_direct;
-    LaneStack stk{lds_stack + threadIdx.x};
+    LaneStack stk{lds_stack + threadIdx.x, S.world + (blockIdx.x * PBRS_TRAVERSAL_BLOCK + threadIdx.x) * 3u};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
-    ClosestWalk<STATS> walk;
+    ClosestWalk<STATS, FEAT> walk;
     walk.mode = PBRS_WALK_IDLE;
     uint32_t slot = 0;
     WaveWork work = wave_work_init(n);
@@ -471,16 +492,16 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
 
 // ---- shadow ----------------------------------------------------------------------------------------------------
 // One work item per shadow ray (persistent, same refill scheme as k_extend); writes one occlusion byte.
-template <bool STATS>
-__global__ void __launch_bounds__(256) k_shadow(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t* next,
+template <bool STATS, uint32_t FEAT>
+__global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t* next,
                                                GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t n = count[1];  // high half of the packed (nee paths, shadow rays) counter
-    LaneStack stk{lds_stack + threadIdx.x};
+    LaneStack stk{lds_stack + threadIdx.x, S.world + (blockIdx.x * PBRS_TRAVERSAL_BLOCK + threadIdx.x) * 3u};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
-    AnyWalk<STATS> walk;
+    AnyWalk<STATS, FEAT> walk;
     walk.mode = PBRS_WALK_IDLE;
     uint32_t item = 0;
     WaveWork work = wave_work_init(n);
@@ -587,24 +608,24 @@ __global__ void __launch_bounds__(256) k_finalize(const float* sum, float* rgb, 
 __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, const float* origins, const float* dirs, const float* tmax,
                                                        pbrs_hit_record* hits, uint8_t* occluded) {
     extern __shared__ uint32_t lds_stack[];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    f3 o = ld3(origins + 3 * i), d = ld3(dirs + 3 * i);
-    LaneStack stk{lds_stack + threadIdx.x};
+    LaneStack stk{lds_stack + threadIdx.x, S.world + (blockIdx.x * PBRS_TRAVERSAL_BLOCK + threadIdx.x) * 3u};
     Cnt<false> cnt;
-    if (hits) {
-        Hit h;
-        tlas_closest<false>(S, o, d, tmax[i], stk, h, cnt);
-        pbrs_hit_record r;
-        r.t = h.t;
-        r.inst = h.inst;
-        r.prim = 0;
-        if (h.inst != 0xffffffffu && S.inst[h.inst].shape_kind == PBRS_SHAPE_MESH) r.prim = S.ts[h.prim].orig;
-        r.b1 = h.b1;
-        r.b2 = h.b2;
-        hits[i] = r;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {  // grid <= PBRS_PERSISTENT_BLOCKS
+        f3 o = ld3(origins + 3 * i), d = ld3(dirs + 3 * i);
+        if (hits) {
+            Hit h;
+            tlas_closest<false>(S, o, d, tmax[i], stk, h, cnt);
+            pbrs_hit_record r;
+            r.t = h.t;
+            r.inst = h.inst;
+            r.prim = 0;
+            if (h.inst != 0xffffffffu && S.inst[h.inst].shape_kind == PBRS_SHAPE_MESH) r.prim = S.ts[h.prim].orig;
+            r.b1 = h.b1;
+            r.b2 = h.b2;
+            hits[i] = r;
+        }
+        if (occluded) occluded[i] = tlas_any<false>(S, o, d, tmax[i], stk, cnt) ? 1 : 0;
     }
-    if (occluded) occluded[i] = tlas_any<false>(S, o, d, tmax[i], stk, cnt) ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(256) k_numeric_eval(uint32_t fn, uint32_t n, const float* x, const float* y, float* out) {

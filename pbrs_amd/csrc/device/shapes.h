@@ -28,7 +28,16 @@ struct DevScene {
     float env[3];
     uint32_t has_env;
     uint32_t fast_slab;  // node coordinates are inside the range the f64-reciprocal box test is exact for (traverse.h)
+    uint32_t features;   // PBRS_FEAT_*: what the traversal kernels must be able to do for this scene
+    uint4* world;        // PBRS_TRAVERSAL_LANES records of 3 x 16 bytes of per-lane scratch (LaneStack::world)
 };
+
+// Scene features the traversal kernels are specialised on (pbrs_upload_scene derives them from the arrays it checks).
+// Code a scene cannot reach still costs registers and issue slots on every wave, so each combination is its own
+// instantiation: a mesh-only scene whose meshes all carry a PBRS_MESH_*_SHADING_OK flag runs the leanest one.
+#define PBRS_FEAT_ANALYTIC 1u       // some instance is an analytic shape (sphere, disk, quad, cuboid, triangle)
+#define PBRS_FEAT_SHADING_CHECK 2u  // some mesh needs the tangent check of blas.rs:193-200 evaluated per candidate hit
+#define PBRS_FEAT_ALL 3u
 
 // Per-lane work counters (instrumented kernel variant only; SURVEY.md §8(d) units).
 struct WorkCounters {
@@ -363,8 +372,14 @@ PD bool mesh_tri_pred(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max) {
 // a wave's 64 accesses to one level hit 64 consecutive dwords — no bank conflicts; the constant stride folds the
 // index arithmetic into the ds_read/ds_write address).
 #define PBRS_TRAVERSAL_BLOCK 256
+// The traversal kernels are persistent: at most this many blocks, each lane keeps pulling rays (kernels.h).
+#define PBRS_PERSISTENT_BLOCKS 1536
+#define PBRS_TRAVERSAL_LANES (PBRS_PERSISTENT_BLOCKS * PBRS_TRAVERSAL_BLOCK)
+#define PBRS_WORLD_WORDS 12
 struct LaneStack {
-    uint32_t* base;  // &lds[threadIdx.x]
+    uint32_t* base;   // &lds[threadIdx.x]
+    uint4* world;     // &S.world[(blockIdx.x * 256 + threadIdx.x) * 3]: the lane's world-space ray waits in this 48-byte
+                      // record while the lane walks an instance (three 16-byte accesses, L2-resident; 13 VGPRs less)
     PD void put(int level, uint32_t v) { base[level * PBRS_TRAVERSAL_BLOCK] = v; }
     PD uint32_t get(int level) const { return base[level * PBRS_TRAVERSAL_BLOCK]; }
 };

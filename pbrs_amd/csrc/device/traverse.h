@@ -50,6 +50,25 @@ PD RaySpace make_space(f3 o, f3 d, bool scene_ok) {
     }
     return r;
 }
+// The world-space ray of a lane that is inside an instance waits in the lane's scratch record (LaneStack::world).
+// `fast` is not stored: make_space leaves the reciprocals at 0.0 exactly when it is false, and 1/d is never 0.
+PD void save_world(LaneStack stk, const RaySpace& r) {
+    stk.world[0] = make_uint4(pn_bits(r.o.x), pn_bits(r.o.y), pn_bits(r.o.z), pn_bits(r.d.x));
+    stk.world[1] = make_uint4(pn_bits(r.d.y), pn_bits(r.d.z), (uint32_t)__double2loint(r.rx), (uint32_t)__double2hiint(r.rx));
+    stk.world[2] = make_uint4((uint32_t)__double2loint(r.ry), (uint32_t)__double2hiint(r.ry), (uint32_t)__double2loint(r.rz),
+                              (uint32_t)__double2hiint(r.rz));
+}
+PD RaySpace load_world(LaneStack stk) {
+    const uint4 a = stk.world[0], b = stk.world[1], c = stk.world[2];
+    RaySpace r;
+    r.o = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+    r.d = mk3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+    r.rx = __hiloint2double((int)b.w, (int)b.z);
+    r.ry = __hiloint2double((int)c.y, (int)c.x);
+    r.rz = __hiloint2double((int)c.w, (int)c.z);
+    r.fast = r.rx != 0.0;
+    return r;
+}
 PD float qdiv(float n, double r) { return (float)((double)n * r); }
 // geometry/src/bvh.rs:84-99 (same min/max/NaN conventions as dmath.h::slab_test)
 PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
@@ -70,11 +89,20 @@ PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
 // bit-exactly the identity the Mat4 products return the operand's own bits as long as every component
 // is finite and non-zero (1*x + 0*y + 0*z + 0*w = x exactly), which is what W.fast plus a non-zero
 // origin guarantee; anything else takes the literal products.
-PD RaySpace enter_instance(const DevScene& S, const pbrs_instance& in, const RaySpace& W) {
-    if ((in.flags & PBRS_INSTANCE_IDENTITY) && W.fast && W.o.x != 0.0f && W.o.y != 0.0f && W.o.z != 0.0f) return W;
-    f3 oo = xf_apply(in.inv, W.o, 1.0f);
-    f3 od = xf_apply(in.inv, W.d, 0.0f);
-    return make_space(oo, od, S.fast_slab != 0);
+// Returns false when the lane's ray is unchanged (C still is the world ray).
+PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, bool need_slab, LaneStack stk) {
+    if ((in.flags & PBRS_INSTANCE_IDENTITY) && C.fast && C.o.x != 0.0f && C.o.y != 0.0f && C.o.z != 0.0f) return false;
+    save_world(stk, C);
+    f3 oo = xf_apply(in.inv, C.o, 1.0f);
+    f3 od = xf_apply(in.inv, C.d, 0.0f);
+    if (need_slab) {
+        C = make_space(oo, od, S.fast_slab != 0);
+    } else {  // an analytic shape: no boxes below the instance, the reciprocals are never read
+        C.o = oo;
+        C.d = od;
+        C.fast = false;
+    }
+    return true;
 }
 
 // Closest hit, as a resumable walk (one lane = one ray; the kernel interleaves many walks per lane, see
@@ -96,21 +124,22 @@ PD RaySpace enter_instance(const DevScene& S, const pbrs_instance& in, const Ray
 #define PBRS_WALK_LEAF 2u
 #define PBRS_WALK_DONE 3u
 
-template <bool STATS>
+template <bool STATS, uint32_t FEAT>
 struct ClosestWalk {
-    RaySpace W, C;  // world ray; C = the space the lane is walking in (W in the TLAS, the instance's ray in a BLAS).
-                    // One box-test call on C serves lanes in either tree: no branch duplicates the test.
+    RaySpace C;  // the space the lane is walking in (the world ray in the TLAS, the instance's ray below a TLAS leaf): one
+                 // box-test call serves lanes in either tree.  The world ray is parked in the lane's scratch meanwhile.
     Hit best;       // best.t stays +inf until the first candidate: `!(best.t < t)` then accepts it, as Option::None does
     float t_max, lt, mt, mb1, mb2;  // lt: the cloned ray's t_max inside intersect_bvh; mt: outer_hit.ray_t
-    uint32_t mprim, cur_inst, mesh_flags;
-    uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or leaf_a = the TLAS leaf's instance
+    uint32_t mprim, cur_inst;
+    uint32_t inst_info;  // of the instance the lane is in: shape kind | mesh flags << 3 | bit 31: an analytic candidate is held
+    uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or leaf_a = the analytic shape
     int sp, blas_base;
-    bool in_blas;
+    bool in_blas, moved;  // moved: C differs from the parked world ray
     uint32_t mode;
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
-        W = make_space(o, d, S.fast_slab != 0);
-        C = W;
+        C = make_space(o, d, S.fast_slab != 0);
+        moved = false;
         best.t = pn_inf();
         best.inst = 0xffffffffu;
         best.prim = 0;
@@ -119,7 +148,7 @@ struct ClosestWalk {
         t_max = tmax;
         lt = 0.0f;
         mt = pn_inf();
-        mprim = cur_inst = mesh_flags = leaf_a = leaf_end = 0;
+        mprim = cur_inst = inst_info = leaf_a = leaf_end = 0;
         mb1 = mb2 = 0.0f;
         blas_base = 0;
         stk.put(0, 0u);
@@ -131,8 +160,10 @@ struct ClosestWalk {
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
         if (in_blas && sp == blas_base) {  // intersect_bvh returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
             in_blas = false;
-            C = W;
-            if (mt < pn_inf()) {
+            if (moved) C = load_world(stk);
+            // a mesh candidate always has t < inf (it beat outer_hit.ray_t = inf); an analytic one may sit at t == +inf
+            // (x / 0 with an infinite extent), so those are flagged
+            if (mt < pn_inf() || (inst_info & 0x80000000u)) {
                 CNT(instance_hits);
                 if (!(best.t < mt)) {
                     best.t = mt;
@@ -168,45 +199,58 @@ struct ClosestWalk {
             leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
             if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
             else lt = mt;  // an empty leaf still runs blas.rs:468
-        } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
-            // Instance::intersect of a mesh (instance.rs:50-53): enter its BLAS without leaving the node state
+        } else {
+            // Instance::intersect (instance.rs:50-67): the ray goes into the instance's space and stays there until the
+            // walk is back at this stack level.  A mesh continues in the node state with its BLAS root; an analytic
+            // shape is one held primitive.  Either way the candidate (mt, ...) meets `best` at the exit above.
             const pbrs_instance& in = S.inst[node.a];
             CNT(instances);
-            C = enter_instance(S, in, W);
+            const uint32_t kind = (node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+            moved = enter_instance(S, in, C, kind == PBRS_SHAPE_MESH, stk);
             in_blas = true;
             blas_base = sp;
             cur_inst = node.a;
-            mesh_flags = in.mesh_flags;
             lt = t_max;
             mt = pn_inf();
-            stk.put(sp++, in.blas_root);
-        } else {
-            leaf_a = node.a;
-            mode = PBRS_WALK_LEAF;
+            if (kind == PBRS_SHAPE_MESH) {
+                inst_info = kind | (in.mesh_flags << 3);
+                stk.put(sp++, in.blas_root);
+            } else if (kind == PBRS_SHAPE_TRIANGLE) {
+                // IsolatedTriangle (simple.rs:417-426): one triangle record, no boxes, no shading frame
+                inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
+                leaf_a = in.blas_root;
+                leaf_end = in.blas_root + 1u;
+                mode = PBRS_WALK_LEAF;
+            } else if (FEAT & PBRS_FEAT_ANALYTIC) {
+                inst_info = kind;
+                leaf_a = in.shape_index;
+                mode = PBRS_WALK_LEAF;
+            }
         }
     }
 
     // One primitive of the held leaf: the next triangle of a BLAS leaf, or the analytic shape of a TLAS leaf.
     PD void leaf_step(const DevScene& S, Cnt<STATS>& cnt) {
-        if (in_blas) {
+        const uint32_t kind = inst_info & 7u;
+        if (!(FEAT & PBRS_FEAT_ANALYTIC) || kind == PBRS_SHAPE_MESH || kind == PBRS_SHAPE_TRIANGLE) {
             const uint32_t ti = leaf_a++;
             if (leaf_a == leaf_end) mode = PBRS_WALK_NODE;
             pbrs_tri_verts tv = load_tri(S.tv + ti);
             CNT(triangles);
             TriHit h;
             bool hit = mesh_tri_hit(tv, C.o, C.d, lt, h);
-            if (hit) CNT(tri_shading);
+            if (hit && kind == PBRS_SHAPE_MESH) CNT(tri_shading);
             // The reference builds the shading frame of every geometric hit (blas.rs:166-206) and drops the
             // hit when the tangent check fails (Q22).  Only a hit that would replace outer_hit can change the
             // result, and for a flat-shaded mesh the check is a host-verified property of the triangles.
             hit = hit && h.t < mt;
-            if (hit && !(mesh_flags & PBRS_MESH_FLAT_SHADING_OK)) {
+            if ((FEAT & PBRS_FEAT_SHADING_CHECK) && hit && !((inst_info >> 3) & PBRS_MESH_SHADING_OK_MASK)) {
                 f3 n, dpdu;
                 hit = mesh_tri_shading(tv, S.ts[ti], C.d, h, n, dpdu);
             }
             if (hit) {
                 mt = h.t;
-                mprim = ti;
+                mprim = kind == PBRS_SHAPE_MESH ? ti : 0u;
                 mb1 = h.b1;
                 mb2 = h.b2;
             }
@@ -215,58 +259,43 @@ struct ClosestWalk {
             return;
         }
         mode = PBRS_WALK_NODE;
-        // Instance::intersect of an analytic shape (instance.rs:50-67)
-        const pbrs_instance& in = S.inst[leaf_a];
-        CNT(instances);
-        f3 oo = xf_apply(in.inv, W.o, 1.0f);
-        f3 od = xf_apply(in.inv, W.d, 0.0f);
-        const float* p = S.shapes[in.shape_index].p;
+        if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
+        // an analytic shape in its own space (C), extent = the TLAS extent at entry (lt)
+        const float* p = S.shapes[leaf_a].p;
         float t = 0.0f, b1 = 0.0f, b2 = 0.0f;
         bool hit = false;
-        switch (in.shape_kind) {
+        switch (kind) {
             case PBRS_SHAPE_SPHERE:
                 CNT(spheres);
-                hit = sphere_hit_t(ld3(p), p[3], oo, od, t_max, t);
+                hit = sphere_hit_t(ld3(p), p[3], C.o, C.d, lt, t);
                 break;
             case PBRS_SHAPE_QUAD: {
                 CNT(quads);
                 float u, v;
                 f3 n;
-                hit = quad_hit(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, t, u, v, n);
+                hit = quad_hit(ld3(p), ld3(p + 3), ld3(p + 6), C.o, C.d, lt, t, u, v, n);
                 break;
             }
             case PBRS_SHAPE_CUBOID: {
                 CNT(cuboids);
                 int axis;
                 float bound;
-                hit = cuboid_hit(ld3(p), ld3(p + 3), oo, od, t_max, t, axis, bound);
+                hit = cuboid_hit(ld3(p), ld3(p + 3), C.o, C.d, lt, t, axis, bound);
                 break;
             }
             case PBRS_SHAPE_DISK:
                 CNT(disks);
-                hit = disk_hit_t(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, t);
+                hit = disk_hit_t(ld3(p), ld3(p + 3), ld3(p + 6), C.o, C.d, lt, t);
                 break;
-            default: {  // PBRS_SHAPE_TRIANGLE
-                CNT(triangles);
-                TriHit h;
-                hit = tri_hit(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max, h);
-                if (hit) {
-                    t = h.t;
-                    b1 = h.b1;
-                    b2 = h.b2;
-                }
+            default:  // PBRS_SHAPE_TRIANGLE never gets here (triangle-record path above)
                 break;
-            }
         }
-        if (!hit) return;
-        CNT(instance_hits);
-        if (!(best.t < t)) {
-            best.t = t;
-            best.inst = leaf_a;
-            best.prim = 0;
-            best.b1 = b1;
-            best.b2 = b2;
-            t_max = t;
+        if (hit) {
+            inst_info |= 0x80000000u;
+            mt = t;
+            mprim = 0;
+            mb1 = b1;
+            mb2 = b2;
         }
     }
 };
@@ -276,23 +305,23 @@ struct ClosestWalk {
 // the visiting order cannot change the answer and nothing is carried between instances, so BLAS children
 // are visited near-first (by the sign of the ray direction on the split axis), which reaches an occluder
 // sooner than the reference's left-first recursion.
-template <bool STATS>
+template <bool STATS, uint32_t FEAT>
 struct AnyWalk {
-    RaySpace W, C;
+    RaySpace C;
     float t_max;
-    uint32_t leaf_a, leaf_end;
+    uint32_t leaf_a, leaf_end, inst_kind;
     int sp, blas_base;
-    bool in_blas, occluded;
+    bool in_blas, occluded, moved;
     uint32_t mode;
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
-        W = make_space(o, d, S.fast_slab != 0);
-        C = W;
+        C = make_space(o, d, S.fast_slab != 0);
+        moved = false;
         t_max = tmax;
         in_blas = false;
         occluded = false;
         blas_base = 0;
-        leaf_a = leaf_end = 0;
+        leaf_a = leaf_end = inst_kind = 0;
         stk.put(0, 0u);
         sp = 1;
         mode = PBRS_WALK_NODE;
@@ -300,7 +329,7 @@ struct AnyWalk {
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
         if (in_blas && sp == blas_base) {
             in_blas = false;
-            C = W;
+            if (moved) C = load_world(stk);
         }
         if (sp == 0) {
             mode = PBRS_WALK_DONE;
@@ -322,56 +351,59 @@ struct AnyWalk {
             leaf_a = node.a;
             leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
             if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
-        } else if (((node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u) == PBRS_SHAPE_MESH) {
+        } else {  // Instance::occludes (instance.rs:68-72)
             const pbrs_instance& in = S.inst[node.a];
             CNT(instances);
-            C = enter_instance(S, in, W);
+            inst_kind = (node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+            moved = enter_instance(S, in, C, inst_kind == PBRS_SHAPE_MESH, stk);
             in_blas = true;
             blas_base = sp;
-            stk.put(sp++, in.blas_root);
-        } else {
-            leaf_a = node.a;
-            mode = PBRS_WALK_LEAF;
+            if (inst_kind == PBRS_SHAPE_MESH) {
+                stk.put(sp++, in.blas_root);
+            } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {  // IsolatedTriangle::occludes (simple.rs:428-433): its triangle record
+                leaf_a = in.blas_root;
+                leaf_end = in.blas_root + 1u;
+                mode = PBRS_WALK_LEAF;
+            } else if (FEAT & PBRS_FEAT_ANALYTIC) {
+                leaf_a = in.shape_index;
+                mode = PBRS_WALK_LEAF;
+            }
         }
     }
     // One primitive; an occluder ends the walk (mode DONE, occluded set).
     PD void leaf_step(const DevScene& S, Cnt<STATS>& cnt) {
         bool hit;
-        if (in_blas) {
+        if (!(FEAT & PBRS_FEAT_ANALYTIC) || inst_kind == PBRS_SHAPE_MESH || inst_kind == PBRS_SHAPE_TRIANGLE) {
             const uint32_t ti = leaf_a++;
             pbrs_tri_verts tv = load_tri(S.tv + ti);
             CNT(triangles);
             hit = mesh_tri_pred(tv, C.o, C.d, t_max);
             mode = leaf_a == leaf_end ? PBRS_WALK_NODE : PBRS_WALK_LEAF;
         } else {
-            const pbrs_instance& in = S.inst[leaf_a];
-            CNT(instances);
-            f3 oo = xf_apply(in.inv, W.o, 1.0f);
-            f3 od = xf_apply(in.inv, W.d, 0.0f);
-            const float* p = S.shapes[in.shape_index].p;
-            switch (in.shape_kind) {
+            mode = PBRS_WALK_NODE;
+            if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
+            const float* p = S.shapes[leaf_a].p;
+            switch (inst_kind) {
                 case PBRS_SHAPE_SPHERE:
                     CNT(spheres);
-                    hit = sphere_occludes(ld3(p), p[3], oo, od, t_max);
+                    hit = sphere_occludes(ld3(p), p[3], C.o, C.d, t_max);
                     break;
                 case PBRS_SHAPE_QUAD:
                     CNT(quads);
-                    hit = quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
+                    hit = quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), C.o, C.d, t_max);
                     break;
                 case PBRS_SHAPE_CUBOID:  // Q14: the bbox slab test
                     CNT(cuboids);
-                    hit = slab_test(ld3(p), ld3(p + 3), oo, od, t_max);
+                    hit = slab_test(ld3(p), ld3(p + 3), C.o, C.d, t_max);
                     break;
                 case PBRS_SHAPE_DISK:
                     CNT(disks);
-                    hit = disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), oo, od);
+                    hit = disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), C.o, C.d);
                     break;
-                default:
-                    CNT(triangles);
-                    hit = tri_pred(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, t_max);
+                default:  // PBRS_SHAPE_TRIANGLE never gets here
+                    hit = false;
                     break;
             }
-            mode = PBRS_WALK_NODE;
         }
         if (hit) {
             occluded = true;
@@ -383,7 +415,7 @@ struct AnyWalk {
 // One ray start to finish (parity harness; the pipeline kernels interleave walks instead).
 template <bool STATS>
 PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
-    ClosestWalk<STATS> w;
+    ClosestWalk<STATS, PBRS_FEAT_ALL> w;
     w.start(S, o, d, t_max, stk);
     while (w.mode != PBRS_WALK_DONE) {
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
@@ -393,7 +425,7 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
 }
 template <bool STATS>
 PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
-    AnyWalk<STATS> w;
+    AnyWalk<STATS, PBRS_FEAT_ALL> w;
     w.start(S, o, d, t_max, stk);
     while (w.mode != PBRS_WALK_DONE) {
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);

@@ -11,6 +11,7 @@
 // Tree shape is semantic (it fixes traversal order, tie-breaks and byte counts), so every f32
 // expression below keeps the reference's operand order; compile with -ffp-contract=off.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -35,6 +36,33 @@ inline float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline float length(V3 a) { return pn_sqrt(dot3(a, a)); }
 inline V3 normalized(V3 a) { return scale(a, 1.0f / length(a)); }  // Vec3::hat, math/src/hcm.rs:112-117
+
+// PBRS_MESH_SMOOTH_SHADING_OK for one triangle (blas.rs:170-200).  A hit's shading normal is
+// n = +-hat(N), N = w0 n0 + w1 n1 + w2 n2 with weights in [-3e-7, 1] that sum to 1 (the normalised same-sign
+// barycentrics of simple.rs:471-480, re-derived as 1 - b1 - b2), or the geometric normal if hat fails.  The
+// reference then forms r = u - n (u.n) / |n|^2 (u = dpdu_raw), dpdu = hat(r), and drops the hit when |dpdu . n| >= 1e-3.
+// In exact arithmetic r is orthogonal to n; in f32 the five roundings of the projection leave |r . n| <= 12 eps |u|
+// while |r| >= |u| (sin(theta) - 12 eps), theta = angle(u, n), so |dpdu . n| <= 12 eps / (sin(theta) - 12 eps) + 4 eps
+// (eps = 2^-24).  This function proves sin(theta) >= 0.0447 (|cos| <= 0.999) for every admissible n:
+//   |u . N| <= |u| (1 + 1e-6) max_i |u^ . n_i|   and   |N|^2 >= g (1 - 1e-5),  g = min_{i,j} n_i . n_j > 0,
+// hence |cos(theta)| <= c_max / sqrt(g) * (1 + 1e-5); it asks for c_max <= 0.99 sqrt(g), which bounds the dropped
+// quantity by 2e-5, fifty times under the threshold.  With g > 0 and sane lengths hat(N) cannot fail, and the
+// geometric normal is checked as well.  Evaluated in double: only the inequality matters, not its rounding.
+bool smooth_shading_bound(V3 u, V3 n0, V3 n1, V3 n2, V3 gn) {
+    auto d3 = [](V3 a, V3 b) { return (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z; };
+    const double L = std::sqrt(d3(u, u));
+    if (!(L >= 1e-10 && L <= 1e15)) return false;
+    const V3 n[3] = {n0, n1, n2};
+    if (!(std::fabs(d3(u, gn)) / L <= 0.99)) return false;  // the fallback normal (unit length)
+    double g = 1e300, lmax = 0.0, cmax = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        cmax = std::max(cmax, std::fabs(d3(u, n[i])) / L);
+        for (int j = i; j < 3; ++j) g = std::min(g, d3(n[i], n[j]));
+        lmax = std::max(lmax, std::sqrt(d3(n[i], n[i])));
+    }
+    if (!(g > 0.0) || !(lmax <= 1e15) || !(std::sqrt(g) >= 1e-10) || !(lmax <= 1e3 * std::sqrt(g))) return false;
+    return cmax <= 0.99 * std::sqrt(g);
+}
 inline V3 v3p(const float* p) { return {p[0], p[1], p[2]}; }
 
 // geometry/src/bvh.rs — glam Vec3A min/max are SSE minps/maxps ("second operand on NaN").
@@ -416,7 +444,7 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
         pm.height = root.second;
         pm.n_nodes = (uint32_t)hs->blas_nodes.size() - node0;
         max_blas_height = std::max(max_blas_height, pm.height);
-        bool flat_ok = true;
+        bool flat_ok = true, smooth_ok = true;
         for (const Tri& t : tris) {
             // `let (i, k, j) = tri.index_triple` (blas.rs:162): vertex order read by the mesh is (i, 3rd, 2nd)
             uint32_t v0 = t.i, v1 = t.k, v2 = t.j;
@@ -447,6 +475,17 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
             ts.uv2[0] = m.uvs[2 * v2]; ts.uv2[1] = m.uvs[2 * v2 + 1];
             ts.orig = t.orig;
             hs->tri_shade.push_back(ts);
+            // dpdu of blas.rs:186-190, a property of the triangle; evaluated with the reference's operand order
+            V3 dpdu_raw;
+            {
+                float u0 = ts.uv0[0], w0 = ts.uv0[1];
+                float u1 = ts.uv1[0] - u0, w1 = ts.uv1[1] - w0;
+                float u2 = ts.uv2[0] - u0, w2 = ts.uv2[1] - w0;
+                float den = u1 * w2 - u2 * w1;
+                V3 num = sub(scale(sub(p2, p0), w2), scale(sub(p1, p0), w1));
+                dpdu_raw = V3{num.x / den, num.y / den, num.z / den};
+                if (!pn_isfinite(dot3(dpdu_raw, dpdu_raw))) dpdu_raw = sub(p1, p0);
+            }
             // PBRS_MESH_FLAT_SHADING_OK: with n0 == n1 == n2 (bitwise) barycentric_lerp returns that normal for any
             // finite barycentrics ((a-c)*b0 + (b-c)*b1 + c = 0 + 0 + c), `facing` only flips its sign, and the
             // projection / hat / abs(dot) of blas.rs:186-193 are invariant under that flip: the Q22 test is a
@@ -459,13 +498,7 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
                     V3 n = n0;
                     float inv_n = 1.0f / length(n0);
                     if (pn_isfinite(inv_n) && inv_n != 0.0f) n = scale(n0, inv_n); else n = gn;  // `.try_hat().unwrap_or(hit.normal)`
-                    float u0 = ts.uv0[0], w0 = ts.uv0[1];
-                    float u1 = ts.uv1[0] - u0, w1 = ts.uv1[1] - w0;
-                    float u2 = ts.uv2[0] - u0, w2 = ts.uv2[1] - w0;
-                    float den = u1 * w2 - u2 * w1;
-                    V3 num = sub(scale(sub(p2, p0), w2), scale(sub(p1, p0), w1));
-                    V3 dpdu{num.x / den, num.y / den, num.z / den};
-                    if (!pn_isfinite(dot3(dpdu, dpdu))) dpdu = sub(p1, p0);
+                    V3 dpdu = dpdu_raw;
                     float dn = dot3(dpdu, n);
                     V3 sn = scale(n, dn);
                     float n2 = dot3(n, n);
@@ -475,12 +508,14 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
                 }
                 flat_ok = same && pass;
             }
+            if (smooth_ok) smooth_ok = !has_normal || smooth_shading_bound(dpdu_raw, v3p(ts.n0), v3p(ts.n1), v3p(ts.n2), gn);
         }
         if (flat_ok) pm.flags |= PBRS_MESH_FLAT_SHADING_OK;
+        if (smooth_ok) pm.flags |= PBRS_MESH_SMOOTH_SHADING_OK;
         hs->meshes.push_back(pm);
     }
     // -- analytic shapes
-    std::vector<uint32_t> shape_slot(spec->n_shapes, 0);
+    std::vector<uint32_t> shape_slot(spec->n_shapes, 0), shape_tri(spec->n_shapes, 0);
     for (uint32_t s = 0; s < spec->n_shapes; ++s) {
         const pbrs_shape_spec& sp = spec->shapes[s];
         if (sp.kind == PBRS_SHAPE_MESH) {
@@ -510,6 +545,24 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
         }
         shape_slot[s] = (uint32_t)hs->shapes.size();
         hs->shapes.push_back(ps);
+        if (sp.kind == PBRS_SHAPE_TRIANGLE) {
+            // IsolatedTriangle::intersect / occludes (simple.rs:417-433) call the same intersect_triangle(_pred) as a mesh
+            // triangle, on (p0, p1, p2) as given: the traversal kernels test it through the triangle record path, so the
+            // shape also gets a record (geometric normal precomputed as for mesh triangles; no shading attributes).
+            V3 p0 = v3p(sp.p), p1 = v3p(sp.p + 3), p2 = v3p(sp.p + 6);
+            pbrs_tri_verts tv{};
+            set3(tv.p0, sp.p);
+            set3(tv.p1, sp.p + 3);
+            set3(tv.p2, sp.p + 6);
+            V3 gn{pn_nan(), pn_nan(), pn_nan()};
+            V3 c = cross3(sub(p0, p1), sub(p2, p1));
+            float inv_length = 1.0f / length(c);
+            if (pn_isfinite(inv_length) && inv_length != 0.0f) gn = scale(c, inv_length);
+            tv.nx = gn.x; tv.ny = gn.y; tv.nz = gn.z;
+            shape_tri[s] = (uint32_t)hs->tri_verts.size();
+            hs->tri_verts.push_back(tv);
+            hs->tri_shade.push_back(pbrs_tri_shade{});
+        }
     }
     // -- materials
     for (uint32_t m = 0; m < spec->n_materials; ++m) {
@@ -541,6 +594,8 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
         if (pi.shape_kind == PBRS_SHAPE_MESH) {
             pi.blas_root = hs->meshes[pi.shape_index].root;
             pi.mesh_flags = hs->meshes[pi.shape_index].flags;
+        } else if (pi.shape_kind == PBRS_SHAPE_TRIANGLE) {
+            pi.blas_root = shape_tri[is.shape];  // its record in tri_verts[]
         }
         {
             static const float kIdentity[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};

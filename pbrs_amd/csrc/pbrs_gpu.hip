@@ -22,7 +22,7 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kMaxDepth = 64;
 constexpr uint32_t kHeadWords = PBRS_WORK_HEADS * PBRS_WORK_HEAD_STRIDE;
 constexpr uint32_t kCounterWords = (3 + 2 * kHeadWords) * (kMaxDepth + 2);  // act, ns (u64), then the work heads
-constexpr uint32_t kPersistentBlocks = 256 * 6;  // 256 CUs x up to 6 resident 256-thread blocks (VGPR/LDS permitting)
+constexpr uint32_t kPersistentBlocks = PBRS_PERSISTENT_BLOCKS;  // 256 CUs x up to 6 resident 256-thread blocks (VGPR/LDS permitting)
 constexpr size_t kLdsBytesPerCU = 160 * 1024;
 
 struct StageEvent {
@@ -49,6 +49,7 @@ struct pbrs_ctx {
     void* state_mem = nullptr;
     PathState st{};
     uint32_t* queues = nullptr;   // 5 * cap_slots: ping, pong, nee, shadow rays (2 per path)
+    uint4* world = nullptr;       // PBRS_TRAVERSAL_LANES x 48 bytes: parked world rays of the traversal lanes
     uint32_t* counters = nullptr; // kCounterWords: act, ns (u64), extend work heads, shadow work heads
     float* sum = nullptr;         // 3 * cap_pixels, planar
     float* rgb_dev = nullptr;     // 3 * cap_pixels, row-major (for the host-output variant)
@@ -159,7 +160,13 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
     return PBRS_OK;
 }
 
-size_t lds_bytes(const pbrs_ctx* c) { return (size_t)(c->stack_depth) * kBlock * sizeof(uint32_t); }
+size_t lds_bytes(const pbrs_ctx* c) {
+    size_t b = (size_t)(c->stack_depth) * kBlock * sizeof(uint32_t);
+#ifdef PBRS_PROBE_LDS_PAD  // developer probe: lowers the occupancy of the traversal kernels
+    if (const char* e = getenv("PBRS_LDS_MIN")) b = b < (size_t)atol(e) ? (size_t)atol(e) : b;
+#endif
+    return b;
+}
 
 uint32_t auto_samples_per_pass(const pbrs_render_params* p);
 
@@ -220,12 +227,41 @@ uint32_t auto_samples_per_pass(const pbrs_render_params* p) {
     uint64_t P = (uint64_t)p->w * p->h, spp = (uint64_t)p->strata_x * p->strata_y;
     uint64_t k = p->samples_per_pass;
     if (k == 0) {
-        const uint64_t target = 4ull << 20;  // ~4M paths in flight: >> 256 CUs x 2048 lanes, < 1 GiB of state
+        // ~32M paths in flight (~7 GB of the 288 GB HBM for state + queues).  Every bounce is a handful of launches
+        // and a persistent traversal kernel ends with the latency of its longest walks (hundreds of dependent node
+        // fetches on a deep BLAS): the fewer, larger launches a frame is cut into, the less of it is spent draining.
+        const uint64_t target = 32ull << 20;
         k = P >= target ? 1 : target / P;
     }
     if (k > spp) k = spp;
     if (k < 1) k = 1;
     return (uint32_t)k;
+}
+
+// The traversal kernels are instantiated per scene-feature set (device/shapes.h PBRS_FEAT_*); the instrumented variant
+// exists for the full set only.  k_shadow never evaluates shading frames, so only PBRS_FEAT_ANALYTIC selects it.
+void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uint32_t* queue, const uint32_t* count, uint32_t n_direct, uint32_t* heads) {
+#define PBRS_LAUNCH_EXTEND(ST, F) \
+    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, queue, count, n_direct, heads, c->gcnt)
+    if (stats) {
+        PBRS_LAUNCH_EXTEND(true, PBRS_FEAT_ALL);
+        return;
+    }
+    switch (c->S.features & PBRS_FEAT_ALL) {
+        case 0u: PBRS_LAUNCH_EXTEND(false, 0u); break;
+        case 1u: PBRS_LAUNCH_EXTEND(false, 1u); break;
+        case 2u: PBRS_LAUNCH_EXTEND(false, 2u); break;
+        default: PBRS_LAUNCH_EXTEND(false, 3u); break;
+    }
+#undef PBRS_LAUNCH_EXTEND
+}
+void launch_shadow(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uint32_t* queue, const uint32_t* count, uint32_t* heads) {
+#define PBRS_LAUNCH_SHADOW(ST, F) \
+    hipLaunchKernelGGL((k_shadow<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, queue, count, heads, c->gcnt + 1)
+    if (stats) PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC);
+    else if (c->S.features & PBRS_FEAT_ANALYTIC) PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC);
+    else PBRS_LAUNCH_SHADOW(false, 0u);
+#undef PBRS_LAUNCH_SHADOW
 }
 
 // One pass: kc sample indices starting at `first` for every pixel of the tile.
@@ -255,20 +291,14 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     for (uint32_t b = 0; b < rc.max_depth; ++b) {
         const uint32_t* qin = b == 0 ? nullptr : q[b & 1];
         if (tm.begin(1)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        if (stats)
-            hipLaunchKernelGGL(k_extend<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, xhead + b * kHeadWords, c->gcnt);
-        else
-            hipLaunchKernelGGL(k_extend<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, qin, act + b, N, xhead + b * kHeadWords, c->gcnt);
+        launch_extend(c, stats, pgrid, lds, qin, act + b, N, xhead + b * kHeadWords);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
         hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], act + b + 1, shq,
                            neeq, ns + b);
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        if (stats)
-            hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords, c->gcnt + 1);
-        else
-            hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(kBlock), lds, c->stream, c->S, c->st, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords, c->gcnt + 1);
+        launch_shadow(c, stats, pgrid, lds, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords);
         hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
         tm.end();
     }
@@ -362,7 +392,8 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     c->total_ev.resize(2);
     if (hipEventCreate(&c->total_ev[0]) != hipSuccess || hipEventCreate(&c->total_ev[1]) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->world), (size_t)PBRS_WORLD_WORDS * PBRS_TRAVERSAL_LANES * sizeof(uint32_t)) != hipSuccess) {
         delete c;
         return PBRS_E_DEVICE;
     }
@@ -378,6 +409,7 @@ void pbrs_destroy(pbrs_ctx* c) {
     free_work(c);
     if (c->counters) (void)hipFree(c->counters);
     if (c->gcnt) (void)hipFree(c->gcnt);
+    if (c->world) (void)hipFree(c->world);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -428,6 +460,8 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         if (in.shape_kind > PBRS_SHAPE_MESH) return fail(c, PBRS_E_INVALID, "unknown shape kind");
         if (in.shape_kind == PBRS_SHAPE_MESH ? in.shape_index >= d->n_meshes : in.shape_index >= d->n_shapes)
             return fail(c, PBRS_E_INVALID, "instance shape out of range");
+        if (in.shape_kind == PBRS_SHAPE_MESH ? in.blas_root >= d->n_blas_nodes : (in.shape_kind == PBRS_SHAPE_TRIANGLE && in.blas_root >= d->n_triangles))
+            return fail(c, PBRS_E_INVALID, "instance blas_root out of range");
     }
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const pbrs_material& m = d->materials[i];
@@ -475,14 +509,26 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             for (int a = 0; a < 3; ++a) ok = ok && coord_ok(d->blas_nodes[i].min[a]) && coord_ok(d->blas_nodes[i].max[a]);
         S.fast_slab = ok ? 1u : 0u;
     }
+    S.world = c->world;
+    S.features = 0;
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+        const pbrs_instance& in = d->instances[i];
+        if (in.shape_kind == PBRS_SHAPE_MESH) {
+            if (!(in.mesh_flags & PBRS_MESH_SHADING_OK_MASK)) S.features |= PBRS_FEAT_SHADING_CHECK;
+        } else if (in.shape_kind != PBRS_SHAPE_TRIANGLE) {  // isolated triangles go through the triangle-record path
+            S.features |= PBRS_FEAT_ANALYTIC;
+        }
+    }
     c->S = S;
     c->stack_depth = depth;
     c->has_scene = true;
     size_t lds = lds_bytes(c);
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shadow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shadow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void* traversal_kernels[] = {
+        reinterpret_cast<const void*>(&k_extend<false, 0u>), reinterpret_cast<const void*>(&k_extend<false, 1u>),
+        reinterpret_cast<const void*>(&k_extend<false, 2u>), reinterpret_cast<const void*>(&k_extend<false, 3u>),
+        reinterpret_cast<const void*>(&k_extend<true, PBRS_FEAT_ALL>), reinterpret_cast<const void*>(&k_shadow<false, 0u>),
+        reinterpret_cast<const void*>(&k_shadow<false, PBRS_FEAT_ANALYTIC>), reinterpret_cast<const void*>(&k_shadow<true, PBRS_FEAT_ANALYTIC>)};
+    for (const void* k : traversal_kernels) HIPCHK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect_rays), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return PBRS_OK;
 }
@@ -545,7 +591,7 @@ int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const flo
     TRY(hipMemcpyAsync(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
     TRY(hipMemcpyAsync(d_d, dirs, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
     TRY(hipMemcpyAsync(d_t, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_intersect_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds_bytes(c), c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ);
+    hipLaunchKernelGGL(k_intersect_rays, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, kPersistentBlocks)), dim3(kBlock), lds_bytes(c), c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ);
     TRY(hipGetLastError());
     if (hits_out) TRY(hipMemcpyAsync(hits_out, d_h, (size_t)n * sizeof(pbrs_hit_record), hipMemcpyDeviceToHost, c->stream));
     if (occluded_out) TRY(hipMemcpyAsync(occluded_out, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));

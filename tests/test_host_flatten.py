@@ -26,7 +26,12 @@ def test_trees_are_well_formed_and_match_the_oracle(name):
     d = hs.desc
     assert d.tlas_height == osc.tlas_height()
     assert d.n_tlas_nodes == 2 * d.n_instances - 1  # binary tree with one instance per leaf (tlas/src/bvh.rs:116-152)
-    for which, n_leaf_items in (("tlas", d.n_instances), ("blas", d.n_triangles)):
+    # tri_verts[] also holds one record per IsolatedTriangle shape (after the mesh triangles): those belong to no BLAS leaf
+    n_mesh_tris = int(_meshes(hs)[:, 3].sum()) if d.n_meshes else 0
+    inst = _instances(hs)
+    n_isolated = len(set(inst[inst[:, 24] == 4, 28].tolist()))
+    assert d.n_triangles >= n_mesh_tris + n_isolated
+    for which, n_leaf_items in (("tlas", d.n_instances), ("blas", n_mesh_tris)):
         boxes, a, b = node_arrays(hs, which)
         if len(a) == 0:
             continue
@@ -113,6 +118,28 @@ def test_precomputed_triangle_normals_and_flags():
     sb, _ = scenes.build_config("c4", width=16, height=16, nx=8, nz=8)
     hs = pbrs_amd.HostScene(sb)
     assert (_meshes(hs)[0, 5] & 1) == 0
+    # ... but the tangent check is provably passed by every hit (normals near the face normal, dpdu in the face plane)
+    assert (_meshes(hs)[0, 5] & 2) != 0
+
+
+def test_shading_flags_of_skewed_normals_and_isolated_triangle_records():
+    """Vertex normals that lean into the tangent direction defeat the smooth-shading bound (the kernels then evaluate
+    blas.rs:193-200 per candidate hit); an IsolatedTriangle shape gets a triangle record that its instance points at."""
+    from pbrs_amd.spec import SceneBuilder, deg
+    sb = SceneBuilder()
+    m = sb.lambertian((0.5, 0.5, 0.5))
+    pos = [(-1, 0, -1), (1, 0, -1), (-1, 0, 1), (1, 0, 1)]
+    uv = [(0, 0), (1, 0), (0, 1), (1, 1)]
+    sb.instance(sb.mesh(pos, [(0, 0.0001 + 0.0002 * k, 1) for k in range(4)], uv, [(0, 1, 2), (2, 1, 3)]), m)  # normals along dpdu
+    sb.instance(sb.mesh(pos, [(0.3, 1, 0), (0, 1, 0.2), (0, 1, 0), (-0.1, 1, 0)], uv, [(0, 1, 2), (2, 1, 3)]), m)  # ordinary smooth normals
+    sb.instance(sb.triangle((-1, 2, 0), (1, 2, 0.5), (0, 3.5, 0)), m)
+    sb.set_camera(8, 8, deg(40.0), (0, 3, -5), (0, 0, 0))
+    hs = pbrs_amd.HostScene(sb)
+    meshes, inst = _meshes(hs), _instances(hs)
+    assert (meshes[0, 5] & 3) == 0 and (meshes[1, 5] & 3) == 2
+    assert hs.desc.n_triangles == 5 and inst[2, 24] == 4 and inst[2, 28] == 4
+    tv = np.ctypeslib.as_array(C.cast(hs.desc.tri_verts, C.POINTER(C.c_float)), shape=(5, 12))
+    assert (tv[4, [0, 1, 2]] == np.float32([-1, 2, 0])).all() and (tv[4, [8, 9, 10]] == np.float32([0, 3.5, 0])).all()
 
 
 def test_degenerate_triangle_gets_nan_normal():
