@@ -24,17 +24,19 @@ struct PathState {
     float* ht;        // hit record
     uint32_t *hinst, *hprim;
     float *hb1, *hb2;
-    // next-event estimation hand-off to the shadow stage
-    float* so[2][3];
-    float* sd[2][3];
+    // Next-event estimation hand-off.  Every shadow ray is one 64-byte record (four 16-byte vectors, written and read
+    // with full-width coalesced accesses at its queue position):
+    //   [0] origin.xyz, t_max          [1] dir.xyz, slot | ray index << 31 | lone << 30
+    //   [2] lone ray: what the path's radiance gains if the ray is unoccluded      [3] ... if it is occluded
+    // A path that casts both of its rays (the two MIS terms of an area light) cannot be finished by either tracing
+    // lane: its terms wait in the columns below and k_nee_resolve combines them with the two occlusion bytes.
+    float4* shadow_rays;
     float* sc[2][3];
-    float* stmax[2];  // < 0: ray not cast
     float* nb[3];     // beta at the time of the estimate
     float* nscale;    // 1 / light_pdf
-    uint32_t* nmode;  // 0 area (sum of the two MIS terms), 1 delta, 2 env
     uint8_t* occ[2];  // written by k_shadow: 1 = the ray is occluded
 };
-#define PBRS_STATE_WORDS 47
+#define PBRS_STATE_WORDS 32
 
 struct RenderConst {
     pbrs_camera cam;
@@ -281,12 +283,16 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 // ---- shade -----------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* queue,
                                               const uint32_t* count, uint32_t n_direct, uint32_t* queue_out, uint32_t* count_out,
-                                              uint32_t* shadow_queue, uint32_t* nee_queue, unsigned long long* nee_shadow_count) {
+                                              uint32_t* nee_queue, unsigned long long* nee_shadow_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = queue ? *count : n_direct;
     bool valid = i < n;
-    bool alive = false, want_shadow = false, cast0 = false, cast1 = false;
+    bool alive = false, cast0 = false, cast1 = false;
     uint32_t slot = 0;
+    ShadowRay sr0, sr1;  // the rays to cast, kept until their queue positions are known
+    sr0.o = sr0.d = sr1.o = sr1.d = gray(0.0f);
+    sr0.t_max = sr1.t_max = -1.0f;
+    f3 add_v = gray(0.0f), add_o = gray(0.0f);
     if (valid) {
         slot = queue ? queue[i] : i;
         f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
@@ -394,27 +400,39 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     c1 = cmul(ld3(S.env), f2) * ac * wr;
                     c2 = cmul(gray(0.0f), f2) * ac * wr;  // Color::black() * f * ..., the occluded arm
                 }
-                if (v1.t_max >= 0.0f || v2.t_max >= 0.0f) {
-                    want_shadow = true;
-                    cast0 = v1.t_max >= 0.0f;
-                    cast1 = v2.t_max >= 0.0f;
+                cast0 = v1.t_max >= 0.0f;
+                cast1 = v2.t_max >= 0.0f;
+                if (cast0 && cast1) {
+                    // two rays (area light, both MIS terms alive): directlighting.rs:193 and :219 add up in k_nee_resolve
                     for (int r = 0; r < 3; ++r) {
-                        st.so[0][r][slot] = comp(v1.o, r);
-                        st.sd[0][r][slot] = comp(v1.d, r);
                         st.sc[0][r][slot] = comp(c1, r);
-                        st.so[1][r][slot] = comp(v2.o, r);
-                        st.sd[1][r][slot] = comp(v2.d, r);
                         st.sc[1][r][slot] = comp(c2, r);
                         st.nb[r][slot] = comp(beta, r);
                     }
-                    st.stmax[0][slot] = v1.t_max;
-                    st.stmax[1][slot] = v2.t_max;
                     st.nscale[slot] = scale;
-                    st.nmode[slot] = mode;
+                } else if (cast0 || cast1) {
+                    // one ray: the lane that traces it finishes the estimate (directlighting.rs:193 / :219 / :90-96, then
+                    // :98 and pathintegrator.rs:35), so both outcomes are evaluated here with the reference's operations
+                    f3 cr = cast0 ? c1 : c2;
+                    f3 one_v, one_o;
+                    if (mode == 0) {
+                        one_o = gray(0.0f);
+                        one_v = gray(0.0f) + cr;
+                    } else if (mode == 1) {
+                        one_o = gray(0.0f);
+                        one_v = cr;
+                    } else {
+                        one_o = c2;
+                        one_v = cr;
+                    }
+                    add_v = cmul(beta, one_v * scale);
+                    add_o = cmul(beta, one_o * scale);
                 } else {
                     // nothing to test: the estimate is black; pathintegrator.rs:35 still adds beta * (black * n)
                     L = L + cmul(beta, gray(0.0f) * scale);
                 }
+                sr0 = v1;
+                sr1 = v2;
             }
 
             // pathintegrator.rs:46-71
@@ -453,8 +471,8 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
     __shared__ uint32_t s_cnt[4][4];   // [wave][alive, nee, cast0, cast1]
     __shared__ uint32_t s_base[4];     // block bases: alive, nee, shadow
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const bool both = cast0 && cast1;  // two rays: k_nee_resolve combines them; a lone ray is resolved by the lane that traces it
-    const uint32_t lone = (want_shadow && !both) ? 0x40000000u : 0u;
+    const bool both = cast0 && cast1;
+    const uint32_t lone = (!both && (cast0 || cast1)) ? 0x40000000u : 0u;
     const uint64_t m_alive = __ballot(alive), m_nee = __ballot(both), m_c0 = __ballot(cast0), m_c1 = __ballot(cast1);
     if (lane == 0) {
         s_cnt[wave][0] = (uint32_t)__popcll(m_alive);
@@ -484,16 +502,31 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
         b_sh += s_cnt[w][2] + s_cnt[w][3];
     }
     if (alive) queue_out[b_alive + lane_prefix(m_alive)] = slot;
-    // one shadow-queue entry per ray to cast (bit 31 = which ray, bit 30 = the path's only ray), one nee-queue entry per two-ray path
     if (both) nee_queue[b_nee + lane_prefix(m_nee)] = slot;
-    if (cast0) shadow_queue[b_sh + lane_prefix(m_c0)] = slot | lone;
-    if (cast1) shadow_queue[b_sh + s_cnt[wave][2] + lane_prefix(m_c1)] = slot | 0x80000000u | lone;
+    if (cast0) {
+        float4* rec = st.shadow_rays + 4ull * (b_sh + lane_prefix(m_c0));
+        rec[0] = make_float4(sr0.o.x, sr0.o.y, sr0.o.z, sr0.t_max);
+        rec[1] = make_float4(sr0.d.x, sr0.d.y, sr0.d.z, __uint_as_float(slot | lone));
+        if (lone) {
+            rec[2] = make_float4(add_v.x, add_v.y, add_v.z, 0.0f);
+            rec[3] = make_float4(add_o.x, add_o.y, add_o.z, 0.0f);
+        }
+    }
+    if (cast1) {
+        float4* rec = st.shadow_rays + 4ull * (b_sh + s_cnt[wave][2] + lane_prefix(m_c1));
+        rec[0] = make_float4(sr1.o.x, sr1.o.y, sr1.o.z, sr1.t_max);
+        rec[1] = make_float4(sr1.d.x, sr1.d.y, sr1.d.z, __uint_as_float(slot | 0x80000000u | lone));
+        if (lone) {
+            rec[2] = make_float4(add_v.x, add_v.y, add_v.z, 0.0f);
+            rec[3] = make_float4(add_o.x, add_o.y, add_o.z, 0.0f);
+        }
+    }
 }
 
 // ---- shadow ----------------------------------------------------------------------------------------------------
 // One work item per shadow ray (persistent, same refill scheme as k_extend); writes one occlusion byte.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t* next,
+__global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(DevScene S, PathState st, const uint32_t* count, uint32_t* next,
                                                GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t n = count[1];  // high half of the packed (nee paths, shadow rays) counter
@@ -503,7 +536,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
     uint32_t nrays = 0;
     AnyWalk<STATS, FEAT> walk;
     walk.mode = PBRS_WALK_IDLE;
-    uint32_t item = 0;
+    uint32_t item = 0, rec = 0;
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
@@ -512,22 +545,10 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
                 const bool occluded = walk.occluded;
                 const uint32_t slot = item & 0x3fffffffu, r = item >> 31;
                 if (item & 0x40000000u) {
-                    // the path's only shadow ray: nothing to wait for, finish the estimate here
-                    // (directlighting.rs:193 / :219 / :90-96, then :98 and pathintegrator.rs:35)
-                    f3 cr = mk3(st.sc[r][0][slot], st.sc[r][1][slot], st.sc[r][2][slot]);
-                    uint32_t mode = st.nmode[slot];
-                    f3 one;
-                    if (mode == 0) {
-                        one = gray(0.0f);
-                        if (!occluded) one = one + cr;
-                    } else if (mode == 1) {
-                        one = occluded ? gray(0.0f) : cr;
-                    } else {
-                        one = occluded ? mk3(st.sc[1][0][slot], st.sc[1][1][slot], st.sc[1][2][slot]) : cr;
-                    }
-                    f3 nb = mk3(st.nb[0][slot], st.nb[1][slot], st.nb[2][slot]);
+                    // the path's only shadow ray: k_shade left both outcomes in the record
+                    const float4 add = st.shadow_rays[4ull * rec + (occluded ? 3u : 2u)];
                     f3 L = ld_col(st.lr, st.lg, st.lb, slot);
-                    L = L + cmul(nb, one * st.nscale[slot]);
+                    L = L + mk3(add.x, add.y, add.z);
                     st_col(st.lr, st.lg, st.lb, slot, L);
                 } else {
                     st.occ[r][slot] = occluded ? 1 : 0;
@@ -537,11 +558,10 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
             if (work.left()) {
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
-                    item = queue[idx];
-                    uint32_t slot = item & 0x3fffffffu, r = item >> 31;
-                    f3 o = mk3(st.so[r][0][slot], st.so[r][1][slot], st.so[r][2][slot]);
-                    f3 d = mk3(st.sd[r][0][slot], st.sd[r][1][slot], st.sd[r][2][slot]);
-                    walk.start(S, o, d, st.stmax[r][slot], stk);
+                    rec = idx;
+                    const float4 q0 = st.shadow_rays[4ull * idx], q1 = st.shadow_rays[4ull * idx + 1];
+                    item = __float_as_uint(q1.w);
+                    walk.start(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, stk);
                     nrays++;
                 }
                 live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
@@ -560,21 +580,13 @@ __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count[0]) return;  // low half of the packed (nee paths, shadow rays) counter
     uint32_t slot = queue[i];
-    bool cast0 = st.stmax[0][slot] >= 0.0f, cast1 = st.stmax[1][slot] >= 0.0f;
-    bool occ0 = cast0 && st.occ[0][slot] != 0, occ1 = cast1 && st.occ[1][slot] != 0;
+    // only area-light estimates cast two rays: Ld = term 1 (light sample, :193) + term 2 (BSDF sample, :219)
+    bool occ0 = st.occ[0][slot] != 0, occ1 = st.occ[1][slot] != 0;
     f3 c1 = mk3(st.sc[0][0][slot], st.sc[0][1][slot], st.sc[0][2][slot]);
     f3 c2 = mk3(st.sc[1][0][slot], st.sc[1][1][slot], st.sc[1][2][slot]);
-    uint32_t mode = st.nmode[slot];
-    f3 one;
-    if (mode == 0) {
-        one = gray(0.0f);
-        if (cast0 && !occ0) one = one + c1;
-        if (cast1 && !occ1) one = one + c2;
-    } else if (mode == 1) {
-        one = occ0 ? gray(0.0f) : c1;
-    } else {
-        one = occ0 ? c2 : c1;
-    }
+    f3 one = gray(0.0f);
+    if (!occ0) one = one + c1;
+    if (!occ1) one = one + c2;
     f3 nb = mk3(st.nb[0][slot], st.nb[1][slot], st.nb[2][slot]);
     f3 L = ld_col(st.lr, st.lg, st.lb, slot);
     L = L + cmul(nb, one * st.nscale[slot]);

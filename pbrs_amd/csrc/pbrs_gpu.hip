@@ -48,7 +48,8 @@ struct pbrs_ctx {
     size_t cap_slots = 0, cap_pixels = 0;
     void* state_mem = nullptr;
     PathState st{};
-    uint32_t* queues = nullptr;   // 5 * cap_slots: ping, pong, nee, shadow rays (2 per path)
+    uint32_t* queues = nullptr;   // 3 * cap_slots: ping, pong, nee
+    float4* shadow_rays = nullptr; // 2 * cap_slots records of 64 bytes (PathState::shadow_rays)
     uint4* world = nullptr;       // PBRS_TRAVERSAL_LANES x 48 bytes: parked world rays of the traversal lanes
     uint32_t* counters = nullptr; // kCounterWords: act, ns (u64), extend work heads, shadow work heads
     float* sum = nullptr;         // 3 * cap_pixels, planar
@@ -101,10 +102,12 @@ void free_scene(pbrs_ctx* c) {
 void free_work(pbrs_ctx* c) {
     if (c->state_mem) (void)hipFree(c->state_mem);
     if (c->queues) (void)hipFree(c->queues);
+    if (c->shadow_rays) (void)hipFree(c->shadow_rays);
     if (c->sum) (void)hipFree(c->sum);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
     c->state_mem = nullptr;
     c->queues = nullptr;
+    c->shadow_rays = nullptr;
     c->sum = nullptr;
     c->rgb_dev = nullptr;
     c->cap_slots = c->cap_pixels = 0;
@@ -115,10 +118,12 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
     if (n_slots > c->cap_slots) {
         if (c->state_mem) (void)hipFree(c->state_mem);
         if (c->queues) (void)hipFree(c->queues);
+        if (c->shadow_rays) (void)hipFree(c->shadow_rays);
         c->state_mem = nullptr;
         c->queues = nullptr;
+        c->shadow_rays = nullptr;
         size_t col = ((n_slots * 4 + 255) / 256) * 256;
-        const size_t n_cols = 6 + 3 + 3 + 2 /*rng*/ + 1 + 5 + 18 + 2 + 3 + 1 + 1 + 1 /*occ bytes*/;
+        const size_t n_cols = 6 + 3 + 3 + 2 /*rng*/ + 1 + 5 + 6 + 3 + 1 + 1 /*occ bytes*/;
         HIPCHK(c, hipMalloc(&c->state_mem, col * n_cols));
         char* base = static_cast<char*>(c->state_mem);
         size_t k = 0;
@@ -133,19 +138,15 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         s.flags = colu();
         s.ht = colf(); s.hinst = colu(); s.hprim = colu(); s.hb1 = colf(); s.hb2 = colf();
         for (int r = 0; r < 2; ++r)
-            for (int a = 0; a < 3; ++a) s.so[r][a] = colf();
-        for (int r = 0; r < 2; ++r)
-            for (int a = 0; a < 3; ++a) s.sd[r][a] = colf();
-        for (int r = 0; r < 2; ++r)
             for (int a = 0; a < 3; ++a) s.sc[r][a] = colf();
-        s.stmax[0] = colf(); s.stmax[1] = colf();
         for (int a = 0; a < 3; ++a) s.nb[a] = colf();
         s.nscale = colf();
-        s.nmode = colu();
         s.occ[0] = reinterpret_cast<uint8_t*>(base + col * k);
         s.occ[1] = s.occ[0] + n_slots;  // the column holds 4 * n_slots bytes
         k += 1;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->queues), 5 * n_slots * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->queues), 3 * n_slots * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow_rays), 2 * n_slots * 4 * sizeof(float4)));
+        c->st.shadow_rays = c->shadow_rays;
         c->cap_slots = n_slots;
     }
     if (n_pixels > c->cap_pixels) {
@@ -255,9 +256,9 @@ void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uin
     }
 #undef PBRS_LAUNCH_EXTEND
 }
-void launch_shadow(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uint32_t* queue, const uint32_t* count, uint32_t* heads) {
+void launch_shadow(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uint32_t* count, uint32_t* heads) {
 #define PBRS_LAUNCH_SHADOW(ST, F) \
-    hipLaunchKernelGGL((k_shadow<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, queue, count, heads, c->gcnt + 1)
+    hipLaunchKernelGGL((k_shadow<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, count, heads, c->gcnt + 1)
     if (stats) PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC);
     else if (c->S.features & PBRS_FEAT_ANALYTIC) PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC);
     else PBRS_LAUNCH_SHADOW(false, 0u);
@@ -282,7 +283,6 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     uint32_t* shead = xhead + stride * kHeadWords;
     uint32_t* q[2] = {c->queues, c->queues + c->cap_slots};
     uint32_t* neeq = c->queues + 2 * c->cap_slots;
-    uint32_t* shq = c->queues + 3 * c->cap_slots;
     HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(uint32_t), c->stream));
     if (tm.begin(0)) return fail(c, PBRS_E_DEVICE, "event record failed");
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, c->st, rc);
@@ -294,11 +294,10 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         launch_extend(c, stats, pgrid, lds, qin, act + b, N, xhead + b * kHeadWords);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], act + b + 1, shq,
-                           neeq, ns + b);
+        hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], act + b + 1, neeq, ns + b);
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        launch_shadow(c, stats, pgrid, lds, shq, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords);
+        launch_shadow(c, stats, pgrid, lds, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords);
         hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
         tm.end();
     }
