@@ -128,39 +128,58 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #define PBRS_SHADE_WAVES 3
 #endif
 
-// One round of the traversal loop.  Lanes in the node state take a node step, then lanes holding a leaf test one
-// primitive.  A step is skipped while fewer than PBRS_NODE_MIN / PBRS_LEAF_MIN lanes want it and the other kind of
-// lane still has work (those lanes wait and the step later runs fuller); with both thresholds at 1 this is the
-// plain "if-if" loop.
-#ifndef PBRS_NODE_MIN
-#define PBRS_NODE_MIN 1
+// One round of the traversal loop ("if-if"): lanes in the node state take a node step, then lanes holding a leaf test
+// one primitive, so lanes in different phases of their walks share the instruction stream.  Lanes waiting at an
+// instance boundary cross it together once PBRS_XFER_MIN of them wait, or when no lane of the wave can do anything else.
+// The thresholds differ per kernel (measured, C2 / C4): closest-hit walks gain from batching both (a triangle test with
+// its four divisions is the longest step and ran at ~14 % lane utilisation unbatched); any-hit walks have a short
+// primitive test and end at the first hit, where waiting costs more than it saves.
+#ifndef PBRS_EXT_XFER_MIN
+#define PBRS_EXT_XFER_MIN 12
 #endif
-#ifndef PBRS_LEAF_MIN
-#define PBRS_LEAF_MIN 1
+#ifndef PBRS_EXT_LEAF_MIN
+#define PBRS_EXT_LEAF_MIN 14
 #endif
-#define PBRS_STEP_WALK(walk, S, stk, cnt)                                                         \
-    do {                                                                                          \
-        if (PBRS_NODE_MIN > 1 || PBRS_LEAF_MIN > 1) {                                             \
-            const uint32_t nn = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_NODE));        \
-            const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));        \
-            const bool do_node = nn >= PBRS_NODE_MIN || nl < PBRS_LEAF_MIN;                       \
-            if (do_node && walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);              \
-            const uint32_t nl2 = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));       \
-            if ((nl2 >= PBRS_LEAF_MIN || !do_node || nn == 0) && walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt); \
-        } else {                                                                                  \
-            PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                     \
-            if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                         \
-            if (walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt);                              \
-        }                                                                                         \
+#ifndef PBRS_SHD_XFER_MIN
+#define PBRS_SHD_XFER_MIN 2
+#endif
+#ifndef PBRS_SHD_LEAF_MIN
+#define PBRS_SHD_LEAF_MIN 4
+#endif
+#define PBRS_STEP_WALK(walk, S, stk, cnt, XFER_MIN, LEAF_MIN)                                                  \
+    do {                                                                                                       \
+        const uint32_t nx = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_XFER));                         \
+        if (nx) {                                                                                              \
+            if (nx >= XFER_MIN || __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF) == 0) { \
+                if (walk.mode == PBRS_WALK_XFER) walk.xfer_step(S, stk, cnt);                                   \
+            }                                                                                                  \
+        }                                                                                                      \
+        PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                                      \
+        if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                                          \
+        if (LEAF_MIN > 1) {                                                                                    \
+            const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                     \
+            if (nl && (nl >= LEAF_MIN || __ballot(walk.mode == PBRS_WALK_NODE) == 0)) {                        \
+                if (walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt);                                       \
+            }                                                                                                  \
+        } else if (walk.mode == PBRS_WALK_LEAF) {                                                              \
+            walk.leaf_step(S, cnt);                                                                            \
+        }                                                                                                      \
     } while (0)
 // developer probe (tools/util_probe.py, instrumented variant only): wave-level executions of the node and leaf steps,
 // stashed in the cuboid / disk counters of a scene that has neither
 #ifdef PBRS_PROBE_UTIL
+#define PBRS_PROBE_ONE(cond, field)                                                                            \
+    do {                                                                                                       \
+        const uint64_t pm = __ballot(cond);                                                                    \
+        if (pm && (threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)pm) - 1)) cnt.c.field++;       \
+    } while (0)
 #define PBRS_PROBE_UTIL_COUNT(walk, cnt)                                                          \
     do {                                                                                          \
         if (STATS) {                                                                              \
-            const uint64_t pn = __ballot(walk.mode == PBRS_WALK_NODE);                            \
-            if (pn && (threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)pn) - 1)) cnt.c.cuboids++; \
+            PBRS_PROBE_ONE(walk.mode == PBRS_WALK_NODE, cuboids);                                 \
+            PBRS_PROBE_ONE(walk.mode == PBRS_WALK_LEAF, disks);                                   \
+            PBRS_PROBE_ONE(walk.mode == PBRS_WALK_XFER, spheres);                                 \
+            PBRS_PROBE_ONE(true, quads);                                                          \
         }                                                                                         \
     } while (0)
 #else
@@ -245,7 +264,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_extend(Dev
     uint32_t slot = 0;
     WaveWork work = wave_work_init(n);
     for (;;) {
-        uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
+        uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
         if (__popcll(live) < PBRS_REFILL_BELOW) {
             if (walk.mode == PBRS_WALK_DONE) {  // finished walks are retired in batches, at refill time
                 const Hit& h = walk.best;
@@ -265,11 +284,11 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_extend(Dev
                     walk.start(S, o, d, pn_inf(), stk);
                     nrays++;
                 }
-                live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
+                live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
             if (live == 0) break;
         }
-        PBRS_STEP_WALK(walk, S, stk, cnt);
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN);
     }
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
 }
@@ -539,7 +558,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
     uint32_t item = 0, rec = 0;
     WaveWork work = wave_work_init(n);
     for (;;) {
-        uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
+        uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
         if (__popcll(live) < PBRS_REFILL_BELOW) {
             if (walk.mode == PBRS_WALK_DONE) {
                 const bool occluded = walk.occluded;
@@ -564,11 +583,11 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
                     walk.start(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, stk);
                     nrays++;
                 }
-                live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF);
+                live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
             if (live == 0) break;
         }
-        PBRS_STEP_WALK(walk, S, stk, cnt);
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN);
     }
     flush_counters<STATS>(cnt, gc, true, nrays, 0u);
 }

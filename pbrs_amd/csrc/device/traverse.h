@@ -123,6 +123,7 @@ PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, 
 #define PBRS_WALK_NODE 1u
 #define PBRS_WALK_LEAF 2u
 #define PBRS_WALK_DONE 3u
+#define PBRS_WALK_XFER 4u  // at an instance boundary: about to enter one (TLAS leaf popped) or to leave one (its entries are used up)
 
 template <bool STATS, uint32_t FEAT>
 struct ClosestWalk {
@@ -156,24 +157,11 @@ struct ClosestWalk {
         mode = PBRS_WALK_NODE;
     }
 
-    // One node: pop, box test, then push the children / hold the leaf / enter the mesh instance.
+    // One node: pop, box test, then push the children / hold the leaf / stop at the instance boundary.
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
-        if (in_blas && sp == blas_base) {  // intersect_bvh returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
-            in_blas = false;
-            if (moved) C = load_world(stk);
-            // a mesh candidate always has t < inf (it beat outer_hit.ray_t = inf); an analytic one may sit at t == +inf
-            // (x / 0 with an infinite extent), so those are flagged
-            if (mt < pn_inf() || (inst_info & 0x80000000u)) {
-                CNT(instance_hits);
-                if (!(best.t < mt)) {
-                    best.t = mt;
-                    best.inst = cur_inst;
-                    best.prim = mprim;
-                    best.b1 = mb1;
-                    best.b2 = mb2;
-                    t_max = mt;
-                }
-            }
+        if (in_blas && sp == blas_base) {  // the instance's entries are used up: leave it (xfer_step)
+            mode = PBRS_WALK_XFER;
+            return;
         }
         if (sp == 0) {
             mode = PBRS_WALK_DONE;
@@ -199,33 +187,59 @@ struct ClosestWalk {
             leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
             if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
             else lt = mt;  // an empty leaf still runs blas.rs:468
-        } else {
-            // Instance::intersect (instance.rs:50-67): the ray goes into the instance's space and stays there until the
-            // walk is back at this stack level.  A mesh continues in the node state with its BLAS root; an analytic
-            // shape is one held primitive.  Either way the candidate (mt, ...) meets `best` at the exit above.
-            const pbrs_instance& in = S.inst[node.a];
-            CNT(instances);
-            const uint32_t kind = (node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
-            moved = enter_instance(S, in, C, kind == PBRS_SHAPE_MESH, stk);
-            in_blas = true;
-            blas_base = sp;
+        } else {  // a TLAS leaf: enter the instance (xfer_step)
             cur_inst = node.a;
-            lt = t_max;
-            mt = pn_inf();
-            if (kind == PBRS_SHAPE_MESH) {
-                inst_info = kind | (in.mesh_flags << 3);
-                stk.put(sp++, in.blas_root);
-            } else if (kind == PBRS_SHAPE_TRIANGLE) {
-                // IsolatedTriangle (simple.rs:417-426): one triangle record, no boxes, no shading frame
-                inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
-                leaf_a = in.blas_root;
-                leaf_end = in.blas_root + 1u;
-                mode = PBRS_WALK_LEAF;
-            } else if (FEAT & PBRS_FEAT_ANALYTIC) {
-                inst_info = kind;
-                leaf_a = in.shape_index;
-                mode = PBRS_WALK_LEAF;
+            inst_info = (node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+            mode = PBRS_WALK_XFER;
+        }
+    }
+
+    // Instance boundary, both directions.  Any one lane crosses a boundary in few of its steps, but some lane of a wave
+    // does in nearly every round; inline, this code (ray transform, reciprocals, scratch traffic) ran for a handful of
+    // lanes each round.  As a state of its own the kernel runs it when enough lanes wait at a boundary (k_extend).
+    PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        mode = PBRS_WALK_NODE;
+        if (in_blas) {  // intersect_bvh / the shape returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
+            in_blas = false;
+            if (moved) C = load_world(stk);
+            // a mesh candidate always has t < inf (it beat outer_hit.ray_t = inf); an analytic one may sit at t == +inf
+            // (x / 0 with an infinite extent), so those are flagged
+            if (mt < pn_inf() || (inst_info & 0x80000000u)) {
+                CNT(instance_hits);
+                if (!(best.t < mt)) {
+                    best.t = mt;
+                    best.inst = cur_inst;
+                    best.prim = mprim;
+                    best.b1 = mb1;
+                    best.b2 = mb2;
+                    t_max = mt;
+                }
             }
+            return;
+        }
+        // Instance::intersect (instance.rs:50-67): the ray goes into the instance's space and stays there until the
+        // walk is back at this stack level.  A mesh continues in the node state with its BLAS root; an analytic
+        // shape is one held primitive.  Either way the candidate (mt, ...) meets `best` at the exit above.
+        const pbrs_instance& in = S.inst[cur_inst];
+        CNT(instances);
+        const uint32_t kind = inst_info;
+        moved = enter_instance(S, in, C, kind == PBRS_SHAPE_MESH, stk);
+        in_blas = true;
+        blas_base = sp;
+        lt = t_max;
+        mt = pn_inf();
+        if (kind == PBRS_SHAPE_MESH) {
+            inst_info = kind | (in.mesh_flags << 3);
+            stk.put(sp++, in.blas_root);
+        } else if (kind == PBRS_SHAPE_TRIANGLE) {
+            // IsolatedTriangle (simple.rs:417-426): one triangle record, no boxes, no shading frame
+            inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
+            leaf_a = in.blas_root;
+            leaf_end = in.blas_root + 1u;
+            mode = PBRS_WALK_LEAF;
+        } else if (FEAT & PBRS_FEAT_ANALYTIC) {
+            leaf_a = in.shape_index;
+            mode = PBRS_WALK_LEAF;
         }
     }
 
@@ -328,8 +342,8 @@ struct AnyWalk {
     }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
         if (in_blas && sp == blas_base) {
-            in_blas = false;
-            if (moved) C = load_world(stk);
+            mode = PBRS_WALK_XFER;
+            return;
         }
         if (sp == 0) {
             mode = PBRS_WALK_DONE;
@@ -351,23 +365,34 @@ struct AnyWalk {
             leaf_a = node.a;
             leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
             if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
-        } else {  // Instance::occludes (instance.rs:68-72)
-            const pbrs_instance& in = S.inst[node.a];
-            CNT(instances);
+        } else {
+            leaf_a = node.a;  // the instance, until xfer_step replaces it by the held primitive
             inst_kind = (node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
-            moved = enter_instance(S, in, C, inst_kind == PBRS_SHAPE_MESH, stk);
-            in_blas = true;
-            blas_base = sp;
-            if (inst_kind == PBRS_SHAPE_MESH) {
-                stk.put(sp++, in.blas_root);
-            } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {  // IsolatedTriangle::occludes (simple.rs:428-433): its triangle record
-                leaf_a = in.blas_root;
-                leaf_end = in.blas_root + 1u;
-                mode = PBRS_WALK_LEAF;
-            } else if (FEAT & PBRS_FEAT_ANALYTIC) {
-                leaf_a = in.shape_index;
-                mode = PBRS_WALK_LEAF;
-            }
+            mode = PBRS_WALK_XFER;
+        }
+    }
+    // Instance::occludes (instance.rs:68-72) and the return from it; see ClosestWalk::xfer_step.
+    PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        mode = PBRS_WALK_NODE;
+        if (in_blas) {
+            in_blas = false;
+            if (moved) C = load_world(stk);
+            return;
+        }
+        const pbrs_instance& in = S.inst[leaf_a];
+        CNT(instances);
+        moved = enter_instance(S, in, C, inst_kind == PBRS_SHAPE_MESH, stk);
+        in_blas = true;
+        blas_base = sp;
+        if (inst_kind == PBRS_SHAPE_MESH) {
+            stk.put(sp++, in.blas_root);
+        } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {  // IsolatedTriangle::occludes (simple.rs:428-433): its triangle record
+            leaf_a = in.blas_root;
+            leaf_end = in.blas_root + 1u;
+            mode = PBRS_WALK_LEAF;
+        } else if (FEAT & PBRS_FEAT_ANALYTIC) {
+            leaf_a = in.shape_index;
+            mode = PBRS_WALK_LEAF;
         }
     }
     // One primitive; an occluder ends the walk (mode DONE, occluded set).
@@ -418,6 +443,7 @@ PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, 
     ClosestWalk<STATS, PBRS_FEAT_ALL> w;
     w.start(S, o, d, t_max, stk);
     while (w.mode != PBRS_WALK_DONE) {
+        if (w.mode == PBRS_WALK_XFER) w.xfer_step(S, stk, cnt);
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
         if (w.mode == PBRS_WALK_LEAF) w.leaf_step(S, cnt);
     }
@@ -428,6 +454,7 @@ PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<
     AnyWalk<STATS, PBRS_FEAT_ALL> w;
     w.start(S, o, d, t_max, stk);
     while (w.mode != PBRS_WALK_DONE) {
+        if (w.mode == PBRS_WALK_XFER) w.xfer_step(S, stk, cnt);
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
         if (w.mode == PBRS_WALK_LEAF) w.leaf_step(S, cnt);
     }
