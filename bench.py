@@ -90,6 +90,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)  # host-side barrier/gather only
+    # one rank per GPU; a rehearsal with more ranks than GPUs (development box) shares the devices round-robin
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -168,12 +170,15 @@ def main():
         # last measured figure for this workload, if any, is read from profiles/ (tools/traffic_from_pmc.py).
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", f"latest_traffic_{args.config}.json")
-        full_size = (W, H, depth) == (scenes.CONFIGS[args.config][2], scenes.CONFIGS[args.config][3], scenes.CONFIGS[args.config][6])
+        full_size = (W, H, sx, sy, depth) == tuple(scenes.CONFIGS[args.config][2:7])  # launch sizes as when it was measured
         if os.path.exists(tpath) and world == 1 and full_size and not args.samples_per_pass:
             with open(tpath) as f:
-                tk = json.load(f)["kernels"].get(dom["kernel"] + "<false>")
+                measured = json.load(f)["kernels"]
+            # the uninstrumented instantiation(s) of the dominant kernel, e.g. "k_extend<false, 0u>"
+            tk = [v for k, v in measured.items() if k == dom["kernel"] or k.startswith(dom["kernel"] + "<false")]
             if tk:
-                traffic, traffic_src = tk["hbm_total"], os.path.relpath(tpath, ROOT)
+                traffic = sum(v["hbm_total"] * v["launches"] for v in tk) / sum(v["launches"] for v in tk)
+                traffic_src = os.path.relpath(tpath, ROOT)
         traversal_ms = (stage_ms["ms_extend"] + stage_ms["ms_shadow"]) / args.steps
         traversal_bytes = roofline.extend_bytes(cst) + roofline.shadow_bytes(cst)
         result = {
