@@ -240,8 +240,14 @@ typedef struct pbrs_render_params {
      * (band_rows rows each) counted from y0, packed:  film_row = y0 + ((r / band_rows) * band_count
      * + band_index) * band_rows + r % band_rows.  band_count <= 1 means a plain rectangular tile. */
     uint32_t band_rows, band_count, band_index;
-    uint32_t pad;
+    uint32_t integrator;           /* PBRS_INTEGRATOR_*: which `fn(&Scene, Ray, i32) -> Color` of src/main.rs:160-163 */
 } pbrs_render_params;
+/* src/pathintegrator.rs:9-74 */
+#define PBRS_INTEGRATOR_PATH 0u
+/* direct_lighting_integrator, src/directlighting.rs:14-47: emission, or the one-light estimate plus one level of perfect
+ * specular reflection/refraction (src/bsdf.rs:104-113) followed by direct_lighting_debug_integrator (:49-56).  max_depth
+ * only gates it (`depth <= 0` returns black); the chain is at most two rays long. */
+#define PBRS_INTEGRATOR_DIRECT 1u
 
 /* Renders a tile; replaces src/main.rs:192-231 for the rows/cols of the tile.  `rgb_out` is
  * w*h*3 floats, row-major.  _host writes to caller-owned host memory (one D2H copy at the end);

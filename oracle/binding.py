@@ -53,6 +53,7 @@ def lib():
         L.oracle_tlas_height.restype = C.c_uint32
         L.oracle_tlas_height.argtypes = [C.c_void_p]
         L.oracle_render_tile.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.oracle_render_tile_integrator.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.oracle_trace_sample.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_uint64, C.c_void_p]
         L.oracle_intersect_rays.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
         L.oracle_camera_rays.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_void_p, C.c_void_p]
@@ -107,12 +108,16 @@ class OracleScene:
     def tlas_height(self):
         return lib().oracle_tlas_height(self._h)
 
-    def render(self, strata_x, strata_y, depth, seed, tile=None, nthreads=None):
+    def render(self, strata_x, strata_y, depth, seed, tile=None, nthreads=None, integrator="path"):
+        """integrator: "path" (src/pathintegrator.rs) or "direct" (direct_lighting_integrator, src/directlighting.rs:14-47)."""
         x0, y0, w, h = tile or (0, 0, self.width, self.height)
         out = np.empty((h, w, 3), dtype=np.float32)
         st = Stats()
         nthreads = nthreads or os.cpu_count() or 1
-        lib().oracle_render_tile(self._h, x0, y0, w, h, strata_x, strata_y, depth, seed, nthreads, out.ctypes.data, C.addressof(st))
+        kind = {"path": 0, "direct": 1}[integrator]
+        rc = lib().oracle_render_tile_integrator(self._h, x0, y0, w, h, strata_x, strata_y, depth, seed, nthreads, kind, out.ctypes.data,
+                                                 C.addressof(st))
+        assert rc == 0
         return out, st.as_dict()
 
     def trace_sample(self, row, col, sample, strata_x, strata_y, depth, seed):

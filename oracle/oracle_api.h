@@ -55,6 +55,9 @@ uint32_t oracle_tlas_height(const oracle_scene*);
 
 int oracle_render_tile(const oracle_scene*, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t strata_x, uint32_t strata_y,
                        uint32_t max_depth, uint64_t seed, uint32_t nthreads, float* rgb_out, oracle_stats* stats_out);
+int oracle_render_tile_integrator(const oracle_scene*, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t strata_x, uint32_t strata_y,
+                                  uint32_t max_depth, uint64_t seed, uint32_t nthreads, uint32_t integrator, float* rgb_out,
+                                  oracle_stats* stats_out);
 int oracle_trace_sample(const oracle_scene*, uint32_t row, uint32_t col, uint32_t sample_index, uint32_t strata_x, uint32_t strata_y,
                         uint32_t max_depth, uint64_t seed, oracle_path_trace* trace);
 int oracle_intersect_rays(const oracle_scene*, uint32_t n, const float* origins, const float* dirs, const float* tmax,

@@ -261,6 +261,45 @@ static Color path_integrator(const Scene& scene, Ray ray, int depth, uint64_t* r
     return radiance;
 }
 
+// ---- src/directlighting.rs:14-56 -------------------------------------------------------------------------
+// direct_lighting_debug_integrator (:49-56): the light estimate at the first hit, or the environment; `_depth` unused.
+static Color direct_lighting_debug_integrator(const Scene& scene, Ray ray, uint64_t* rng) {
+    Hit h;
+    REF_COUNT(closest_rays);
+    if (scene.tlas->intersect(ray, &h)) {
+        REF_COUNT(shade_events);
+        return uniform_sample_one_light(h.isect, *h.inst->mtl, scene, rng);
+    }
+    return scene.eval_env_light(ray);
+}
+// direct_lighting_integrator (:14-47): emitters return their emission; everything else the one-light estimate plus one
+// level of perfect-specular reflection/refraction followed by the debug integrator.
+static Color direct_lighting_integrator(const Scene& scene, Ray ray, int depth, uint64_t* rng) {
+    if (depth <= 0) return black();
+    Hit h;
+    REF_COUNT(closest_rays);
+    if (!scene.tlas->intersect(ray, &h)) return scene.eval_env_light(ray);
+    REF_COUNT(shade_events);
+    const Interaction& hit = h.isect;
+    const Material& mtl = *h.inst->mtl;
+    if (!is_black(mtl.emission())) return mtl.emission();
+    Color direct = uniform_sample_one_light(hit, mtl, scene, rng);
+    std::vector<BXDF> bxdfs = mtl.bxdfs_at(hit);
+    BSDF bsdf = bsdf_new_frame(hit);
+    bsdf.bxdfs = &bxdfs;
+    Color spec_refl = black();
+    Color f;
+    Vec3 wi;
+    Prob pr{};
+    if (bsdf.sample_specular(hit.wo, &f, &wi, &pr)) {
+        REF_ASSERT(pr.is_mass);
+        Ray refl_ray = spawn_ray(hit, wi);
+        Color s = direct_lighting_debug_integrator(scene, refl_ray, rng);
+        spec_refl = s * f * pn_weak_recip(pr.v);
+    }
+    return direct + spec_refl;
+}
+
 }  // namespace ref
 
 // ===== C entry points ========================================================================================
@@ -298,6 +337,15 @@ static void copy_counters(const Counters& c, const Diag& d, oracle_stats* out) {
 // the reference's `i / msaa`, `i % msaa` stratification (:197-201).
 int oracle_render_tile(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t strata_x, uint32_t strata_y,
                        uint32_t max_depth, uint64_t seed, uint32_t nthreads, float* rgb_out, oracle_stats* stats_out) {
+    return oracle_render_tile_integrator(os, x0, y0, w, h, strata_x, strata_y, max_depth, seed, nthreads, 0, rgb_out, stats_out);
+}
+
+// `integrator`: 0 = path_integrator (src/pathintegrator.rs), 1 = direct_lighting_integrator (src/directlighting.rs:14-47);
+// both fit the reference's seam `fn(&Scene, Ray, i32) -> Color` (src/main.rs:160-163).
+int oracle_render_tile_integrator(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t strata_x,
+                                  uint32_t strata_y, uint32_t max_depth, uint64_t seed, uint32_t nthreads, uint32_t integrator,
+                                  float* rgb_out, oracle_stats* stats_out) {
+    if (integrator > 1) return -1;
     const Scene& scene = *os->scene;
     if (nthreads == 0) nthreads = 1;
     const uint32_t width = scene.camera.width;
@@ -323,7 +371,8 @@ int oracle_render_tile(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_
                     Ray ray;
                     scene.camera.shoot_ray(row, col, jx, jy, &ray);
                     REF_COUNT(samples);
-                    color_sum = color_sum + path_integrator(scene, ray, (int)max_depth, &rng, nullptr);
+                    color_sum = color_sum + (integrator == 0 ? path_integrator(scene, ray, (int)max_depth, &rng, nullptr)
+                                                             : direct_lighting_integrator(scene, ray, (int)max_depth, &rng));
                 }
                 Color color = color_sum * (1.0f / (float)spp);  // scale_down_by, color.rs:90-95
                 float* px = rgb_out + 3 * ((size_t)ry * w + cx);

@@ -169,6 +169,7 @@ struct BSDF {
     Color eval(Vec3 wo, Vec3 wi) const;                                              // :43-51
     float pdf(Vec3 wo, Vec3 wi) const;                                               // :53-57
     void sample(Vec3 wo_world, float u, float v, Color* f, Vec3* wi, Prob* pr) const;  // :59-103
+    bool sample_specular(Vec3 wo_world, Color* f, Vec3* wi, Prob* pr) const;           // :104-113
     Omega world_to_local(Vec3 w) const;                                              // :114-118
     Vec3 local_to_world(Omega l) const;                                              // :120-124
 };

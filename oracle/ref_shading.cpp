@@ -426,6 +426,20 @@ void BXDF::sample(Omega wo, float r0, float r1, Color* f, Omega* wi, Prob* pr) c
 }
 
 // ---- src/bsdf.rs ---------------------------------------------------------------------------------------
+// src/bsdf.rs:104-113: the first Specular lobe, sampled with rnd2 = (0.0, 0.0); None when the material has none.
+bool BSDF::sample_specular(Vec3 wo_world, Color* f, Vec3* wi, Prob* pr) const {
+    Omega wo = world_to_local(wo_world);
+    for (const BXDF& bxdf : *bxdfs) {
+        if (bxdf.kind == BXDF::Specular) {
+            Omega wi_local;
+            bxdf.sample(wo, 0.0f, 0.0f, f, &wi_local, pr);
+            *wi = local_to_world(wi_local);
+            return true;
+        }
+    }
+    return false;
+}
+
 BSDF bsdf_new_frame(const Interaction& isect) {  // :18-31
     Vec3 normal = hat(isect.normal);
     Vec3 bitangent = hat(cross(isect.normal, tangent(isect)));

@@ -60,7 +60,7 @@ class RenderParams(C.Structure):
     _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32), ("strata_x", C.c_uint32),
                 ("strata_y", C.c_uint32), ("max_depth", C.c_uint32), ("samples_per_pass", C.c_uint32), ("seed", C.c_uint64),
                 ("collect_counters", C.c_uint32), ("time_stages", C.c_uint32),
-                ("band_rows", C.c_uint32), ("band_count", C.c_uint32), ("band_index", C.c_uint32), ("pad", C.c_uint32)]
+                ("band_rows", C.c_uint32), ("band_count", C.c_uint32), ("band_index", C.c_uint32), ("integrator", C.c_uint32)]
 
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("inst", np.uint32), ("prim", np.uint32), ("b1", np.float32), ("b2", np.float32)])
@@ -125,6 +125,9 @@ def gpu_lib():
         L.pbrs_render_sample_radiance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _gpu = L
     return _gpu
+
+
+INTEGRATORS = {"path": 0, "direct": 1}  # PBRS_INTEGRATOR_*
 
 
 class HostScene:
@@ -192,7 +195,8 @@ class Context:
         self._check(self._L.pbrs_upload_scene(self._h, C.addressof(host_scene.desc)), "pbrs_upload_scene")
         self.scene = host_scene
 
-    def _params(self, strata_x, strata_y, depth, seed, tile, samples_per_pass=0, counters=False, timing=False, bands=None):
+    def _params(self, strata_x, strata_y, depth, seed, tile, samples_per_pass=0, counters=False, timing=False, bands=None,
+                integrator="path"):
         x0, y0, w, h = tile or (0, 0, self.scene.width, self.scene.height)
         p = RenderParams()
         if bands:
@@ -200,12 +204,15 @@ class Context:
         p.x0, p.y0, p.w, p.h = x0, y0, w, h
         p.strata_x, p.strata_y, p.max_depth, p.samples_per_pass = strata_x, strata_y, depth, samples_per_pass
         p.seed, p.collect_counters, p.time_stages = seed, int(counters), int(timing)
+        p.integrator = INTEGRATORS[integrator]
         return p
 
-    def render(self, strata_x, strata_y, depth, seed, tile=None, samples_per_pass=0, counters=False, timing=False, bands=None):
+    def render(self, strata_x, strata_y, depth, seed, tile=None, samples_per_pass=0, counters=False, timing=False, bands=None,
+               integrator="path"):
         """-> (h, w, 3) f32 radiance, stats dict.  Host output (one D2H copy at the end).
-        bands = (band_rows, band_count, band_index): the tile's rows are interleaved row bands."""
-        p = self._params(strata_x, strata_y, depth, seed, tile, samples_per_pass, counters, timing, bands)
+        bands = (band_rows, band_count, band_index): the tile's rows are interleaved row bands.
+        integrator: "path" (src/pathintegrator.rs) or "direct" (direct_lighting_integrator, src/directlighting.rs:14-47)."""
+        p = self._params(strata_x, strata_y, depth, seed, tile, samples_per_pass, counters, timing, bands, integrator)
         out = np.empty((p.h, p.w, 3), dtype=np.float32)
         st = Stats()
         self._check(self._L.pbrs_render_tile(self._h, C.addressof(self.scene.camera), C.addressof(p), out.ctypes.data, C.addressof(st)),
@@ -213,9 +220,9 @@ class Context:
         return out, st.as_dict()
 
     def render_device(self, rgb_device_ptr, strata_x, strata_y, depth, seed, tile=None, samples_per_pass=0, counters=False,
-                      timing=False, bands=None):
+                      timing=False, bands=None, integrator="path"):
         """Asynchronous: the result lands in caller-owned device memory on the context's stream."""
-        p = self._params(strata_x, strata_y, depth, seed, tile, samples_per_pass, counters, timing, bands)
+        p = self._params(strata_x, strata_y, depth, seed, tile, samples_per_pass, counters, timing, bands, integrator)
         self._check(self._L.pbrs_render_tile_device(self._h, C.addressof(self.scene.camera), C.addressof(p), C.c_void_p(rgb_device_ptr), None),
                     "pbrs_render_tile_device")
 
@@ -244,8 +251,8 @@ class Context:
                     "pbrs_camera_rays")
         return o, d
 
-    def sample_radiance(self, sample, strata_x, strata_y, depth, seed, tile=None):
-        p = self._params(strata_x, strata_y, depth, seed, tile)
+    def sample_radiance(self, sample, strata_x, strata_y, depth, seed, tile=None, integrator="path"):
+        p = self._params(strata_x, strata_y, depth, seed, tile, integrator=integrator)
         out = np.empty((p.h, p.w, 3), dtype=np.float32)
         self._check(self._L.pbrs_render_sample_radiance(self._h, C.addressof(self.scene.camera), C.addressof(p), sample, out.ctypes.data),
                     "pbrs_render_sample_radiance")

@@ -279,6 +279,19 @@ PD Bsdf bsdf_new_frame(const Isect& is, const pbrs_bxdf* lobes, uint32_t n) {  /
 }
 PD f3 world_to_local(const Bsdf& b, f3 w) { return hat(mk3(dot(b.c0, w), dot(b.c1, w), dot(b.c2, w))); }  // :114-118
 PD f3 local_to_world(const Bsdf& b, f3 l) { return l.x * b.c0 + l.y * b.c1 + l.z * b.c2; }                 // :120-124
+// src/bsdf.rs:104-113: the first Specular lobe sampled with rnd2 = (0.0, 0.0); false when the material has none
+PD bool bsdf_sample_specular(const Bsdf& b, f3 wo_world, f3& f, f3& wi_out, ProbD& pr) {
+    f3 wo = world_to_local(b, wo_world);
+    for (uint32_t i = 0; i < b.n; ++i) {
+        if (b.lobes[i].kind == PBRS_BXDF_SPECULAR) {
+            f3 wi;
+            bxdf_sample(b.lobes[i], wo, 0.0f, 0.0f, f, wi, pr);
+            wi_out = local_to_world(b, wi);
+            return true;
+        }
+    }
+    return false;
+}
 PD f3 bsdf_eval(const Bsdf& b, f3 wo_w, f3 wi_w) {                                                          // :43-51
     f3 wi = world_to_local(b, wi_w);
     f3 wo = world_to_local(b, wo_w);

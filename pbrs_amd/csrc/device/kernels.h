@@ -34,9 +34,10 @@ struct PathState {
     float* sc[2][3];
     float* nb[3];     // beta at the time of the estimate
     float* nscale;    // 1 / light_pdf
+    float* npost;     // factor applied after beta * estimate (1 for the path integrator; the direct integrator's 1 / mass)
     uint8_t* occ[2];  // written by k_shadow: 1 = the ray is occluded
 };
-#define PBRS_STATE_WORDS 32
+#define PBRS_STATE_WORDS 33
 
 struct RenderConst {
     pbrs_camera cam;
@@ -47,6 +48,7 @@ struct RenderConst {
     uint32_t n_pixels;           // P
     uint32_t n_slots;            // P * K of this pass
     uint32_t band_rows, band_count, band_index;  // interleaved row bands (pbrs_render_params)
+    uint32_t integrator;                         // PBRS_INTEGRATOR_*
     uint64_t seed;
 };
 
@@ -300,6 +302,7 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 }
 
 // ---- shade -----------------------------------------------------------------------------------------------------
+template <uint32_t INTEG>
 __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* queue,
                                               const uint32_t* count, uint32_t n_direct, uint32_t* queue_out, uint32_t* count_out,
                                               uint32_t* nee_queue, unsigned long long* nee_shadow_count) {
@@ -326,11 +329,28 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
         bool specular_bounce = (flags & 1u) != 0;
         const pbrs_material* mat = nullptr;
         if (has_hit) mat = S.mats + S.inst[h.inst].material;
-        if (bounce == 0 || specular_bounce) {  // pathintegrator.rs:19-22
-            f3 e = has_hit ? ld3(mat->emission) : ld3(S.env);
-            L = L + cmul(beta, e);
+        // The direct-lighting integrator (INTEG 1, src/directlighting.rs:14-56) runs on the same stage: bounce 0 is
+        // direct_lighting_integrator, bounce 1 the debug integrator behind one specular lobe.  Its result is
+        // direct + (S * f) * (1 / mass): f travels in the beta columns, 1 / mass in the flags column (as float bits).
+        bool emitter_hit = false;
+        float post = 1.0f;
+        if (INTEG == PBRS_INTEGRATOR_PATH) {
+            if (bounce == 0 || specular_bounce) {  // pathintegrator.rs:19-22
+                f3 e = has_hit ? ld3(mat->emission) : ld3(S.env);
+                L = L + cmul(beta, e);
+            }
+        } else if (bounce == 0) {
+            if (!has_hit) {
+                L = ld3(S.env);  // scene.eval_env_light(ray), directlighting.rs:45
+            } else if (!is_black(ld3(mat->emission))) {
+                L = ld3(mat->emission);  // :27-28
+                emitter_hit = true;
+            }
+        } else {
+            post = __uint_as_float(flags);
+            if (!has_hit) L = L + cmul(ld3(S.env), beta) * post;  // :54, then spec_refl * f * pr.mass().weak_recip() (:37)
         }
-        if (has_hit) {
+        if (has_hit && !emitter_hit) {
             uint64_t rng = st.rng[slot];
 #ifdef PBRS_ABL_NO_RECON  // timing-only ablation build: skips the Interaction rebuild, results are wrong
             Isect is;
@@ -429,6 +449,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                         st.nb[r][slot] = comp(beta, r);
                     }
                     st.nscale[slot] = scale;
+                    st.npost[slot] = post;
                 } else if (cast0 || cast1) {
                     // one ray: the lane that traces it finishes the estimate (directlighting.rs:193 / :219 / :90-96, then
                     // :98 and pathintegrator.rs:35), so both outcomes are evaluated here with the reference's operations
@@ -446,14 +467,35 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     }
                     add_v = cmul(beta, one_v * scale);
                     add_o = cmul(beta, one_o * scale);
+                    if (INTEG != PBRS_INTEGRATOR_PATH) {
+                        add_v = add_v * post;
+                        add_o = add_o * post;
+                    }
                 } else {
                     // nothing to test: the estimate is black; pathintegrator.rs:35 still adds beta * (black * n)
-                    L = L + cmul(beta, gray(0.0f) * scale);
+                    f3 z = cmul(beta, gray(0.0f) * scale);
+                    if (INTEG != PBRS_INTEGRATOR_PATH) z = z * post;
+                    L = L + z;
                 }
                 sr0 = v1;
                 sr1 = v2;
             }
 
+            if (INTEG != PBRS_INTEGRATOR_PATH) {
+                // directlighting.rs:31-41: one level of perfect specular reflection / refraction
+                f3 f, wi;
+                ProbD pr;
+                if (bounce == 0 && bsdf_sample_specular(bs, is.wo, f, wi, pr)) {
+                    f3 no, nd;
+                    spawn_ray(is, wi, no, nd);
+                    alive = true;
+                    st_col(st.ox, st.oy, st.oz, slot, no);
+                    st_col(st.dx, st.dy, st.dz, slot, nd);
+                    st_col(st.br, st.bg, st.bb, slot, f);
+                    st.rng[slot] = rng;
+                    st.flags[slot] = __float_as_uint(pn_weak_recip(pr.v));
+                }
+            } else {
             // pathintegrator.rs:46-71
             float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);
             f3 f, wi;
@@ -480,6 +522,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     st.rng[slot] = rng;
                     st.flags[slot] = specular_bounce ? 1u : 0u;
                 }
+            }
             }
         }
         st_col(st.lr, st.lg, st.lb, slot, L);
@@ -608,7 +651,7 @@ __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_
     if (!occ1) one = one + c2;
     f3 nb = mk3(st.nb[0][slot], st.nb[1][slot], st.nb[2][slot]);
     f3 L = ld_col(st.lr, st.lg, st.lb, slot);
-    L = L + cmul(nb, one * st.nscale[slot]);
+    L = L + cmul(nb, one * st.nscale[slot]) * st.npost[slot];  // npost is 1 for the path integrator: x * 1 == x bit for bit
     st_col(st.lr, st.lg, st.lb, slot, L);
 }
 

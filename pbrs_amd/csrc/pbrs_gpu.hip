@@ -123,7 +123,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         c->queues = nullptr;
         c->shadow_rays = nullptr;
         size_t col = ((n_slots * 4 + 255) / 256) * 256;
-        const size_t n_cols = 6 + 3 + 3 + 2 /*rng*/ + 1 + 5 + 6 + 3 + 1 + 1 /*occ bytes*/;
+        const size_t n_cols = 6 + 3 + 3 + 2 /*rng*/ + 1 + 5 + 6 + 3 + 2 + 1 /*occ bytes*/;
         HIPCHK(c, hipMalloc(&c->state_mem, col * n_cols));
         char* base = static_cast<char*>(c->state_mem);
         size_t k = 0;
@@ -141,6 +141,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
             for (int a = 0; a < 3; ++a) s.sc[r][a] = colf();
         for (int a = 0; a < 3; ++a) s.nb[a] = colf();
         s.nscale = colf();
+        s.npost = colf();
         s.occ[0] = reinterpret_cast<uint8_t*>(base + col * k);
         s.occ[1] = s.occ[0] + n_slots;  // the column holds 4 * n_slots bytes
         k += 1;
@@ -185,6 +186,7 @@ int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* 
     }
     if (p->strata_x == 0 || p->strata_y == 0) return fail(c, PBRS_E_INVALID, "zero strata");
     if (p->max_depth > kMaxDepth) return fail(c, PBRS_E_LIMIT, "max_depth above 64");
+    if (p->integrator > PBRS_INTEGRATOR_DIRECT) return fail(c, PBRS_E_INVALID, "unknown integrator");
     if ((uint64_t)p->w * p->h > (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile above 2^28 pixels");
     // queue entries keep two flag bits next to the slot index
     if ((uint64_t)p->w * p->h * auto_samples_per_pass(p) >= (1ull << 30)) return fail(c, PBRS_E_LIMIT, "tile x samples_per_pass above 2^30 paths");
@@ -221,6 +223,7 @@ RenderConst make_const(const pbrs_camera* cam, const pbrs_render_params* p) {
     rc.n_pixels = p->w * p->h;
     rc.band_rows = p->band_rows; rc.band_count = p->band_count; rc.band_index = p->band_index;
     rc.seed = p->seed;
+    rc.integrator = p->integrator;
     return rc;
 }
 
@@ -288,13 +291,20 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, c->st, rc);
     tm.end();
     const size_t lds = lds_bytes(c);
-    for (uint32_t b = 0; b < rc.max_depth; ++b) {
+    // the direct-lighting integrator is at most two rays deep whatever `depth` says (directlighting.rs:15-17, :36, :49)
+    const uint32_t n_bounces = rc.integrator == PBRS_INTEGRATOR_DIRECT ? (rc.max_depth ? 2u : 0u) : rc.max_depth;
+    for (uint32_t b = 0; b < n_bounces; ++b) {
         const uint32_t* qin = b == 0 ? nullptr : q[b & 1];
         if (tm.begin(1)) return fail(c, PBRS_E_DEVICE, "event record failed");
         launch_extend(c, stats, pgrid, lds, qin, act + b, N, xhead + b * kHeadWords);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], act + b + 1, neeq, ns + b);
+        if (rc.integrator == PBRS_INTEGRATOR_DIRECT)
+            hipLaunchKernelGGL(k_shade<PBRS_INTEGRATOR_DIRECT>, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N,
+                               q[(b + 1) & 1], act + b + 1, neeq, ns + b);
+        else
+            hipLaunchKernelGGL(k_shade<PBRS_INTEGRATOR_PATH>, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N,
+                               q[(b + 1) & 1], act + b + 1, neeq, ns + b);
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
         launch_shadow(c, stats, pgrid, lds, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords);
@@ -339,7 +349,8 @@ int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params*
     if (c->pending_times) HIPCHK(c, hipEventRecord(c->total_ev[1], c->stream));
     HIPCHK(c, hipGetLastError());
     c->pending.passes = passes;
-    c->pending.launches_extend = c->pending.launches_shade = c->pending.launches_shadow = passes * p->max_depth;
+    c->pending.launches_extend = c->pending.launches_shade = c->pending.launches_shadow =
+        passes * (p->integrator == PBRS_INTEGRATOR_DIRECT ? (p->max_depth ? 2u : 0u) : p->max_depth);
     return PBRS_OK;
 }
 

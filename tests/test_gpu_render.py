@@ -98,6 +98,72 @@ def test_materials_and_lights_outside_the_baseline_scenes(gpu_ctx):
         assert (bits(img)[~nan_ref] == bits(ref)[~nan_ref]).all(), variant
 
 
+def _specular_scene(variant):
+    """Mirror sphere, glass sphere, mirror quad mesh and a dielectric-coated (uber: transmit + reflect) box in front of the
+    camera, so that direct_lighting_integrator's specular arm (src/directlighting.rs:31-41) is taken for many pixels."""
+    from pbrs_amd.spec import SceneBuilder, Transform, deg
+    sb = SceneBuilder()
+    floor = sb.lambertian((0.5, 0.45, 0.4))
+    sb.instance(scenes.quad_mesh(sb, (-8, 0, -8), (8, 0, -8), (-8, 0, 8), (8, 0, 8), (0, 1, 0)), floor)
+    sb.instance(scenes.quad_mesh(sb, (-8, 0, 6), (8, 0, 6), (-8, 8, 6), (8, 8, 6), (0, 0, -1)), sb.lambertian((0.2, 0.5, 0.7)))
+    sb.instance(sb.sphere((0, 0, 0), 1.0), sb.mirror((0.9, 0.9, 0.9)), Transform.translater((-2.4, 1.0, 0.5)))
+    sb.instance(sb.sphere((0, 0, 0), 1.0), sb.dielectric(1.5), Transform.translater((0.0, 1.0, -0.5)))
+    sb.instance(scenes.quad_mesh(sb, (1.5, 0.2, 2), (4.5, 0.2, 1), (1.5, 3.2, 2), (4.5, 3.2, 1), (-0.316, 0, -0.949)), sb.mirror((0.8, 0.85, 0.9)))
+    sb.instance(sb.cuboid((-0.6, 0, -0.6), (0.6, 1.2, 0.6)), sb.uber((0.3, 0.1, 0.1), (0.2, 0.2, 0.2), kr=(0.6, 0.6, 0.6), kt=(0.5, 0.5, 0.5),
+                                                                       rough=(0.1, 0.1), eta=1.3, opacity=0.6),
+                Transform().rotate_y(deg(25)).translate((2.2, 0, -1.5)))
+    e = (9.0, 8.0, 7.0)
+    if variant == 0:      # one triangle light: lone shadow rays
+        t = sb.triangle((-1, 5, -1), (1, 5, 1), (1, 5, -1))
+        sb.instance(t, sb.diffuse_light(e))
+        sb.area_light(e, t)
+    elif variant == 1:    # sphere lights: two-ray (both MIS terms) estimates behind the specular lobe
+        for k in range(2):
+            s = sb.sphere((-2.5 + 5 * k, 4.5, 0.5), 0.7)
+            sb.instance(s, sb.diffuse_light(e))
+            sb.area_light(e, s)
+    else:                 # delta lights + environment (no emitter surfaces: the env branch asserts non-empty lobes, :81)
+        sb.point_light((1, 4, -2), (40, 40, 35))
+        sb.distant_light((0.3, -1.0, 0.4), (1.5, 1.5, 1.2), 12.0)
+        sb.env = (0.2, 0.3, 0.5)
+    sb.set_camera(96, 64, deg(55.0), (0.3, 2.2, -7), (0, 1, 0))
+    return sb
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_direct_lighting_integrator_matches_oracle(gpu_ctx, variant):
+    """The reference's other integrator behind the same seam (src/main.rs:160-163): emission, or the one-light estimate
+    plus one level of perfect specular reflection / refraction; same kernels, PBRS_INTEGRATOR_DIRECT."""
+    sb = _specular_scene(variant)
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    ref, ost = osc.render(2, 2, 5, 3, integrator="direct")
+    img, st = gpu_ctx.render(2, 2, 5, 3, integrator="direct", counters=True)
+    assert ost["panics"] == 0 and ost["tlas_ties"] == 0
+    n_primary = 96 * 64 * 4
+    assert ost["closest_rays"] > n_primary + n_primary // 20, "the specular arm is taken"
+    assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"] and st["shade_events"] == ost["shade_events"]
+    assert l2(img, ref) < L2_TOL
+    assert (bits(img) == bits(ref)).all()
+    # depth only gates it (directlighting.rs:15-17); it is a different estimator from the path integrator
+    img1, _ = gpu_ctx.render(2, 2, 1, 3, integrator="direct")
+    assert (bits(img1) == bits(img)).all()
+    img0, _ = gpu_ctx.render(2, 2, 0, 3, integrator="direct")
+    assert not img0.any()
+    path, _ = gpu_ctx.render(2, 2, 5, 3)
+    assert (bits(path) != bits(img)).any()
+
+
+@pytest.mark.parametrize("cfg,w,h", [("c1", 96, 96), ("c2", 96, 96), ("c5", 96, 54)])
+def test_direct_lighting_integrator_on_baseline_scenes(gpu_ctx, cfg, w, h):
+    sb, _ = scenes.build_config(cfg, width=w, height=h)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    ref, ost = OracleScene(sb).render(2, 2, 5, 9, integrator="direct")
+    img, _ = gpu_ctx.render(2, 2, 5, 9, integrator="direct", samples_per_pass=3)  # uneven passes
+    assert ost["panics"] == 0
+    assert (bits(img) == bits(ref)).all()
+
+
 def test_tiles_passes_and_bands_do_not_change_the_image(gpu_ctx):
     """The RNG is keyed by film pixel and sample index: any tiling, any samples_per_pass and any GPU count give
     the same bits (the multi-GPU correctness argument)."""

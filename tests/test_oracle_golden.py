@@ -64,3 +64,18 @@ def test_edge_cases():
     # the only light is the constant environment: corner pixels see it directly (pathintegrator.rs:19-22)
     assert np.allclose(img[0, 0], [0.25, 0.5, 1.0])
     assert st["panics"] == 0
+
+
+def test_direct_lighting_integrator_reduces_to_depth_one_path_tracing_without_specular_lobes():
+    """direct_lighting_integrator (src/directlighting.rs:14-47) on a scene whose camera rays meet no Specular lobe is
+    emission-or-one-light-estimate: exactly what path_integrator computes with depth 1 (emitters carry no lobes, so their
+    light estimate is black)."""
+    from pbrs_amd import scenes
+    sb, _ = scenes.build_config("c2", width=48, height=48)
+    osc = OracleScene(sb)
+    a, sa = osc.render(2, 2, 1, 5, integrator="path")
+    b, sb_ = osc.render(2, 2, 5, 5, integrator="direct")
+    assert (bits(a) == bits(b)).all()
+    assert sb_["closest_rays"] == 48 * 48 * 4 and sb_["panics"] == 0
+    z, _ = osc.render(2, 2, 0, 5, integrator="direct")
+    assert not z.any()
