@@ -67,11 +67,21 @@ PD uint32_t wave_append(bool pred, uint32_t* counter) {
     return base + lane_prefix(mask);
 }
 
-PD f3 ld_col(const float* a, const float* b, const float* c, uint32_t i) { return mk3(a[i], b[i], c[i]); }
+// Column access by path slot.  Slots stay below 2^30 (check_params), so the byte offset fits 32 bits: written as
+// base + zext(slot << 2) the access compiles to the scalar-base form (global_load_dword v, v_off, s[base:base+1]) with
+// ONE shared offset register per slot instead of a 64-bit address computed per column.
+template <class T>
+PD T& at(T* base, uint32_t slot) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 1, "column element size");
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)(uint32_t)(slot * (uint32_t)sizeof(T)));
+}
+PD f3 ld_col(const float* a, const float* b, const float* c, uint32_t i) {
+    return mk3(at(const_cast<float*>(a), i), at(const_cast<float*>(b), i), at(const_cast<float*>(c), i));
+}
 PD void st_col(float* a, float* b, float* c, uint32_t i, f3 v) {
-    a[i] = v.x;
-    b[i] = v.y;
-    c[i] = v.z;
+    at(a, i) = v.x;
+    at(b, i) = v.y;
+    at(c, i) = v.z;
 }
 
 // ---- raygen --------------------------------------------------------------------------------------------------
@@ -95,8 +105,8 @@ __global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
     st_col(st.dx, st.dy, st.dz, slot, dir);
     st_col(st.br, st.bg, st.bb, slot, gray(1.0f));
     st_col(st.lr, st.lg, st.lb, slot, gray(0.0f));
-    st.rng[slot] = rng;
-    st.flags[slot] = 0u;
+    at(st.rng, slot) = rng;
+    at(st.flags, slot) = 0u;
 }
 
 struct GlobalCounters {  // instrumented variant only
@@ -271,11 +281,11 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_extend(Dev
             if (walk.mode == PBRS_WALK_DONE) {  // finished walks are retired in batches, at refill time
                 const Hit& h = walk.best;
                 nhit += h.inst != 0xffffffffu ? 1u : 0u;
-                st.ht[slot] = h.t;
-                st.hinst[slot] = h.inst;
-                st.hprim[slot] = h.prim;
-                st.hb1[slot] = h.b1;
-                st.hb2[slot] = h.b2;
+                at(st.ht, slot) = h.t;
+                at(st.hinst, slot) = h.inst;
+                at(st.hprim, slot) = h.prim;
+                at(st.hb1, slot) = h.b1;
+                at(st.hb2, slot) = h.b2;
                 walk.mode = PBRS_WALK_IDLE;
             }
             if (work.left()) {
@@ -320,11 +330,11 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
         f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
         f3 beta = ld_col(st.br, st.bg, st.bb, slot);
         f3 L = ld_col(st.lr, st.lg, st.lb, slot);
-        uint32_t flags = st.flags[slot];
+        uint32_t flags = at(st.flags, slot);
         Hit h;
-        h.t = st.ht[slot];
-        h.inst = st.hinst[slot];
-        h.prim = st.hprim[slot];
+        h.t = at(st.ht, slot);
+        h.inst = at(st.hinst, slot);
+        h.prim = at(st.hprim, slot);
         bool has_hit = h.inst != 0xffffffffu;
         bool specular_bounce = (flags & 1u) != 0;
         const pbrs_material* mat = nullptr;
@@ -351,7 +361,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
             if (!has_hit) L = L + cmul(ld3(S.env), beta) * post;  // :54, then spec_refl * f * pr.mass().weak_recip() (:37)
         }
         if (has_hit && !emitter_hit) {
-            uint64_t rng = st.rng[slot];
+            uint64_t rng = at(st.rng, slot);
 #ifdef PBRS_ABL_NO_RECON  // timing-only ablation build: skips the Interaction rebuild, results are wrong
             Isect is;
             is.pos = o + h.t * d;
@@ -444,12 +454,12 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                 if (cast0 && cast1) {
                     // two rays (area light, both MIS terms alive): directlighting.rs:193 and :219 add up in k_nee_resolve
                     for (int r = 0; r < 3; ++r) {
-                        st.sc[0][r][slot] = comp(c1, r);
-                        st.sc[1][r][slot] = comp(c2, r);
-                        st.nb[r][slot] = comp(beta, r);
+                        at(st.sc[0][r], slot) = comp(c1, r);
+                        at(st.sc[1][r], slot) = comp(c2, r);
+                        at(st.nb[r], slot) = comp(beta, r);
                     }
-                    st.nscale[slot] = scale;
-                    st.npost[slot] = post;
+                    at(st.nscale, slot) = scale;
+                    at(st.npost, slot) = post;
                 } else if (cast0 || cast1) {
                     // one ray: the lane that traces it finishes the estimate (directlighting.rs:193 / :219 / :90-96, then
                     // :98 and pathintegrator.rs:35), so both outcomes are evaluated here with the reference's operations
@@ -492,8 +502,8 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     st_col(st.ox, st.oy, st.oz, slot, no);
                     st_col(st.dx, st.dy, st.dz, slot, nd);
                     st_col(st.br, st.bg, st.bb, slot, f);
-                    st.rng[slot] = rng;
-                    st.flags[slot] = __float_as_uint(pn_weak_recip(pr.v));
+                    at(st.rng, slot) = rng;
+                    at(st.flags, slot) = __float_as_uint(pn_weak_recip(pr.v));
                 }
             } else {
             // pathintegrator.rs:46-71
@@ -519,8 +529,8 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     st_col(st.ox, st.oy, st.oz, slot, no);
                     st_col(st.dx, st.dy, st.dz, slot, nd);
                     st_col(st.br, st.bg, st.bb, slot, beta);
-                    st.rng[slot] = rng;
-                    st.flags[slot] = specular_bounce ? 1u : 0u;
+                    at(st.rng, slot) = rng;
+                    at(st.flags, slot) = specular_bounce ? 1u : 0u;
                 }
             }
             }
@@ -613,7 +623,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
                     L = L + mk3(add.x, add.y, add.z);
                     st_col(st.lr, st.lg, st.lb, slot, L);
                 } else {
-                    st.occ[r][slot] = occluded ? 1 : 0;
+                    at(st.occ[r], slot) = occluded ? 1 : 0;
                 }
                 walk.mode = PBRS_WALK_IDLE;
             }
@@ -643,15 +653,15 @@ __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_
     if (i >= count[0]) return;  // low half of the packed (nee paths, shadow rays) counter
     uint32_t slot = queue[i];
     // only area-light estimates cast two rays: Ld = term 1 (light sample, :193) + term 2 (BSDF sample, :219)
-    bool occ0 = st.occ[0][slot] != 0, occ1 = st.occ[1][slot] != 0;
-    f3 c1 = mk3(st.sc[0][0][slot], st.sc[0][1][slot], st.sc[0][2][slot]);
-    f3 c2 = mk3(st.sc[1][0][slot], st.sc[1][1][slot], st.sc[1][2][slot]);
+    bool occ0 = at(st.occ[0], slot) != 0, occ1 = at(st.occ[1], slot) != 0;
+    f3 c1 = mk3(at(st.sc[0][0], slot), at(st.sc[0][1], slot), at(st.sc[0][2], slot));
+    f3 c2 = mk3(at(st.sc[1][0], slot), at(st.sc[1][1], slot), at(st.sc[1][2], slot));
     f3 one = gray(0.0f);
     if (!occ0) one = one + c1;
     if (!occ1) one = one + c2;
-    f3 nb = mk3(st.nb[0][slot], st.nb[1][slot], st.nb[2][slot]);
+    f3 nb = mk3(at(st.nb[0], slot), at(st.nb[1], slot), at(st.nb[2], slot));
     f3 L = ld_col(st.lr, st.lg, st.lb, slot);
-    L = L + cmul(nb, one * st.nscale[slot]) * st.npost[slot];  // npost is 1 for the path integrator: x * 1 == x bit for bit
+    L = L + cmul(nb, one * at(st.nscale, slot)) * at(st.npost, slot);  // npost is 1 for the path integrator: x * 1 == x bit for bit
     st_col(st.lr, st.lg, st.lb, slot, L);
 }
 
