@@ -28,6 +28,14 @@ struct DevScene {
     float env[3];
     uint32_t has_env;
     uint32_t fast_slab;  // node coordinates are inside the range the f64-reciprocal box test is exact for (traverse.h)
+    // Small TLAS (<= PBRS_FLAT_TLAS_MAX instances): its leaves alone, in pre-order = the order the tree walk reaches them.
+    // A box inside a box that a ray misses is missed too (each slab bound is a correctly rounded, hence monotonic,
+    // function of the box coordinate), so testing every leaf in this order processes exactly the leaves, in exactly the
+    // order, of the reference's recursion (tlas/src/bvh.rs:84-88) without visiting the inner nodes.  Only for rays on
+    // the division-free box test (no NaN quotients); other rays walk the tree.  Built for PBRS_FLAT_TLAS_MIN..MAX
+    // instances (n_flat = 0 otherwise; kernels without PBRS_FEAT_FLAT_TLAS do not contain the scan).
+    const pbrs_node* tlas_flat;
+    uint32_t n_flat;
     uint32_t features;   // PBRS_FEAT_*: what the traversal kernels must be able to do for this scene
     uint4* world;        // PBRS_TRAVERSAL_LANES records of 3 x 16 bytes of per-lane scratch (LaneStack::world)
 };
@@ -37,7 +45,10 @@ struct DevScene {
 // instantiation: a mesh-only scene whose meshes all carry a PBRS_MESH_*_SHADING_OK flag runs the leanest one.
 #define PBRS_FEAT_ANALYTIC 1u       // some instance is an analytic shape (sphere, disk, quad, cuboid, triangle)
 #define PBRS_FEAT_SHADING_CHECK 2u  // some mesh needs the tangent check of blas.rs:193-200 evaluated per candidate hit
-#define PBRS_FEAT_ALL 3u
+#define PBRS_FEAT_FLAT_TLAS 4u      // DevScene::tlas_flat is built: rays on the division-free box test scan the TLAS leaves
+#define PBRS_FEAT_ALL 7u
+#define PBRS_FLAT_TLAS_MIN 8u   // below this the tree walk visits about as many nodes as there are leaves
+#define PBRS_FLAT_TLAS_MAX 16u
 
 // Per-lane work counters (instrumented kernel variant only; SURVEY.md §8(d) units).
 struct WorkCounters {

@@ -135,6 +135,7 @@ struct ClosestWalk {
     uint32_t inst_info;  // of the instance the lane is in: shape kind | mesh flags << 3 | bit 31: an analytic candidate is held
     uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or leaf_a = the analytic shape
     int sp, blas_base;
+    uint32_t tl;          // next leaf of DevScene::tlas_flat (== n_flat when the lane walks the TLAS tree instead)
     bool in_blas, moved;  // moved: C differs from the parked world ray
     uint32_t mode;
 
@@ -152,8 +153,14 @@ struct ClosestWalk {
         mprim = cur_inst = inst_info = leaf_a = leaf_end = 0;
         mb1 = mb2 = 0.0f;
         blas_base = 0;
-        stk.put(0, 0u);
-        sp = 1;
+        if ((FEAT & PBRS_FEAT_FLAT_TLAS) && S.n_flat != 0u && C.fast) {
+            tl = 0;
+            sp = 0;
+        } else {
+            tl = (FEAT & PBRS_FEAT_FLAT_TLAS) ? S.n_flat : 0u;
+            stk.put(0, 0u);
+            sp = 1;
+        }
         mode = PBRS_WALK_NODE;
     }
 
@@ -163,12 +170,20 @@ struct ClosestWalk {
             mode = PBRS_WALK_XFER;
             return;
         }
-        if (sp == 0) {
-            mode = PBRS_WALK_DONE;
-            return;
+        uint32_t ni;
+        const pbrs_node* nodes;
+        if (sp == 0) {  // not inside an instance (its exit was taken above)
+            if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || tl >= S.n_flat) {
+                mode = PBRS_WALK_DONE;
+                return;
+            }
+            ni = tl++;
+            nodes = S.tlas_flat;
+        } else {
+            ni = stk.get(--sp);
+            nodes = in_blas ? S.blas : S.tlas;
         }
-        const uint32_t ni = stk.get(--sp);
-        const pbrs_node node = load_node((in_blas ? S.blas : S.tlas) + ni);
+        const pbrs_node node = load_node(nodes + ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
@@ -325,6 +340,7 @@ struct AnyWalk {
     float t_max;
     uint32_t leaf_a, leaf_end, inst_kind;
     int sp, blas_base;
+    uint32_t tl;
     bool in_blas, occluded, moved;
     uint32_t mode;
 
@@ -336,8 +352,14 @@ struct AnyWalk {
         occluded = false;
         blas_base = 0;
         leaf_a = leaf_end = inst_kind = 0;
-        stk.put(0, 0u);
-        sp = 1;
+        if ((FEAT & PBRS_FEAT_FLAT_TLAS) && S.n_flat != 0u && C.fast) {
+            tl = 0;
+            sp = 0;
+        } else {
+            tl = (FEAT & PBRS_FEAT_FLAT_TLAS) ? S.n_flat : 0u;
+            stk.put(0, 0u);
+            sp = 1;
+        }
         mode = PBRS_WALK_NODE;
     }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
@@ -345,12 +367,20 @@ struct AnyWalk {
             mode = PBRS_WALK_XFER;
             return;
         }
+        uint32_t ni;
+        const pbrs_node* nodes;
         if (sp == 0) {
-            mode = PBRS_WALK_DONE;
-            return;
+            if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || tl >= S.n_flat) {
+                mode = PBRS_WALK_DONE;
+                return;
+            }
+            ni = tl++;
+            nodes = S.tlas_flat;
+        } else {
+            ni = stk.get(--sp);
+            nodes = in_blas ? S.blas : S.tlas;
         }
-        const uint32_t ni = stk.get(--sp);
-        const pbrs_node node = load_node((in_blas ? S.blas : S.tlas) + ni);
+        const pbrs_node node = load_node(nodes + ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);

@@ -255,16 +255,28 @@ void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uin
         case 0u: PBRS_LAUNCH_EXTEND(false, 0u); break;
         case 1u: PBRS_LAUNCH_EXTEND(false, 1u); break;
         case 2u: PBRS_LAUNCH_EXTEND(false, 2u); break;
-        default: PBRS_LAUNCH_EXTEND(false, 3u); break;
+        case 3u: PBRS_LAUNCH_EXTEND(false, 3u); break;
+        case 4u: PBRS_LAUNCH_EXTEND(false, 4u); break;
+        case 5u: PBRS_LAUNCH_EXTEND(false, 5u); break;
+        case 6u: PBRS_LAUNCH_EXTEND(false, 6u); break;
+        default: PBRS_LAUNCH_EXTEND(false, 7u); break;
     }
 #undef PBRS_LAUNCH_EXTEND
 }
 void launch_shadow(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uint32_t* count, uint32_t* heads) {
 #define PBRS_LAUNCH_SHADOW(ST, F) \
     hipLaunchKernelGGL((k_shadow<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, count, heads, c->gcnt + 1)
-    if (stats) PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC);
-    else if (c->S.features & PBRS_FEAT_ANALYTIC) PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC);
-    else PBRS_LAUNCH_SHADOW(false, 0u);
+    // k_shadow never evaluates shading frames: PBRS_FEAT_SHADING_CHECK does not select it
+    if (stats) {
+        PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS);
+        return;
+    }
+    switch (c->S.features & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS)) {
+        case 0u: PBRS_LAUNCH_SHADOW(false, 0u); break;
+        case PBRS_FEAT_ANALYTIC: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC); break;
+        case PBRS_FEAT_FLAT_TLAS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_FLAT_TLAS); break;
+        default: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS); break;
+    }
 #undef PBRS_LAUNCH_SHADOW
 }
 
@@ -520,7 +532,15 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         S.fast_slab = ok ? 1u : 0u;
     }
     S.world = c->world;
-    S.features = 0;
+    if (d->n_instances >= PBRS_FLAT_TLAS_MIN && d->n_instances <= PBRS_FLAT_TLAS_MAX) {  // DevScene::tlas_flat: the leaves in node-index (= pre-order) order
+        std::vector<pbrs_node> flat;
+        for (uint32_t i = 0; i < d->n_tlas_nodes; ++i)
+            if (d->tlas_nodes[i].b & PBRS_LEAF_FLAG) flat.push_back(d->tlas_nodes[i]);
+        if ((rc = upload(c, flat.data(), (uint32_t)flat.size(), &S.tlas_flat))) return rc;
+        S.n_flat = (uint32_t)flat.size();
+    }
+    const uint32_t flat_feature = S.n_flat ? PBRS_FEAT_FLAT_TLAS : 0u;
+    S.features = flat_feature;
     for (uint32_t i = 0; i < d->n_instances; ++i) {
         const pbrs_instance& in = d->instances[i];
         if (in.shape_kind == PBRS_SHAPE_MESH) {
@@ -536,8 +556,13 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     const void* traversal_kernels[] = {
         reinterpret_cast<const void*>(&k_extend<false, 0u>), reinterpret_cast<const void*>(&k_extend<false, 1u>),
         reinterpret_cast<const void*>(&k_extend<false, 2u>), reinterpret_cast<const void*>(&k_extend<false, 3u>),
-        reinterpret_cast<const void*>(&k_extend<true, PBRS_FEAT_ALL>), reinterpret_cast<const void*>(&k_shadow<false, 0u>),
-        reinterpret_cast<const void*>(&k_shadow<false, PBRS_FEAT_ANALYTIC>), reinterpret_cast<const void*>(&k_shadow<true, PBRS_FEAT_ANALYTIC>)};
+        reinterpret_cast<const void*>(&k_extend<false, 4u>), reinterpret_cast<const void*>(&k_extend<false, 5u>),
+        reinterpret_cast<const void*>(&k_extend<false, 6u>), reinterpret_cast<const void*>(&k_extend<false, 7u>),
+        reinterpret_cast<const void*>(&k_extend<true, PBRS_FEAT_ALL>),
+        reinterpret_cast<const void*>(&k_shadow<false, 0u>), reinterpret_cast<const void*>(&k_shadow<false, PBRS_FEAT_ANALYTIC>),
+        reinterpret_cast<const void*>(&k_shadow<false, PBRS_FEAT_FLAT_TLAS>),
+        reinterpret_cast<const void*>(&k_shadow<false, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>),
+        reinterpret_cast<const void*>(&k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>)};
     for (const void* k : traversal_kernels) HIPCHK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect_rays), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return PBRS_OK;

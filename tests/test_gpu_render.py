@@ -32,7 +32,14 @@ def test_image_matches_golden_and_counters(gpu_ctx, name):
     # identical traversal => identical work counts (the oracle lumps closest + shadow traversal together)
     assert st["closest_rays"] == want["closest_rays"] and st["shadow_rays"] == want["shadow_rays"]
     assert st["shade_events"] == want["shade_events"] and st["samples"] == want["samples"]
-    assert st["tlas_nodes"] + st["shadow_tlas_nodes"] == want["tlas_nodes"]
+    hs = pbrs_amd.HostScene(sb)
+    if not 8 <= hs.desc.n_instances <= 16:
+        assert st["tlas_nodes"] + st["shadow_tlas_nodes"] == want["tlas_nodes"]
+    else:
+        # a TLAS of 8..16 instances is scanned leaf by leaf in pre-order (same leaves, same order, no inner-node visits:
+        # DevScene::tlas_flat) by every ray that is on the division-free box test; the others walk the tree
+        assert st["tlas_nodes"] + st["shadow_tlas_nodes"] <= want["tlas_nodes"]
+    assert st["instances"] + st["shadow_instances"] == want["instances"]
     # any-hit visits BLAS children near-first (order-free for a boolean), so only its ray and TLAS counts are
     # comparable with the reference's left-first recursion; closest-hit counts are comparable in full
     assert st["blas_nodes"] <= want["blas_nodes"] and st["triangles"] <= want["triangles"]
