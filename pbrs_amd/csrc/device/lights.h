@@ -161,7 +161,13 @@ PD bool area_radiance_to(const pbrs_area_light& L, const Isect& target, f3 wi, f
     spawn_ray(target, wi, o, d);
     LightPoint hit;
     if (!light_shape_intersect(L, o, d, hit)) return false;
-    if (!light_pdf_at(L, target, wi, pdf)) return false;
+    if (L.shape_kind == PBRS_SHAPE_SPHERE) {
+        if (!sphere_pdf_at(ld3(L.p), L.p[3], target.pos, wi, pdf)) return false;
+    } else {
+        // the default pdf_at (sample_shape.rs:28-33) spawns the same ray from the same point and intersects the same
+        // shape again: a pure function of the same operands, so its hit is `hit`
+        pdf = norm(target.pos - hit.pos) / (pn_abs(dot(hit.normal, -wi)) * L.area);
+    }
     vis = limited_ray_to(target, hit.pos);
     le = ld3(L.emit);
     return true;

@@ -250,3 +250,26 @@ def test_full_size_c4_million_triangle_window(gpu_ctx):
     assert ost["panics"] == 0 and ost["tlas_ties"] == 0
     assert (bits(a) == bits(ref)).all()
     assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+
+
+@pytest.mark.parametrize("cfg,windows", [
+    ("c3", [(300, 700, 64, 8), (40, 200, 64, 8)]),           # glass sphere / plastic box region, mirror on the red wall
+    ("c4", [(900, 600, 64, 8)]),
+    ("c5", [(1800, 1400, 64, 8), (600, 300, 64, 8)]),        # objects on the floor, lights
+])
+def test_full_size_frames_against_oracle_windows(gpu_ctx, cfg, windows):
+    """BASELINE sizes (1024x1024, 1920x1080 with 1 M triangles, 3840x2160 with 130 instances) as whole frames at 4 spp:
+    finite, deterministic across pass sizes, and equal to the oracle bit for bit wherever the oracle is evaluated."""
+    sb, c = scenes.build_config(cfg)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    a, st = gpu_ctx.render(2, 2, c["depth"], 3, counters=True)
+    assert a.shape == (c["height"], c["width"], 3)
+    assert np.isfinite(a).all()
+    assert st["samples"] == c["width"] * c["height"] * 4
+    b, _ = gpu_ctx.render(2, 2, c["depth"], 3, samples_per_pass=1)
+    assert (bits(a) == bits(b)).all()
+    osc = OracleScene(sb)
+    for (x0, y0, w, h) in windows:
+        ref, ost = osc.render(2, 2, c["depth"], 3, tile=(x0, y0, w, h))
+        assert ost["panics"] == 0
+        assert (bits(a[y0:y0 + h, x0:x0 + w]) == bits(ref)).all(), (cfg, x0, y0)
