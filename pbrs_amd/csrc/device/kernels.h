@@ -305,6 +305,21 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_extend(Dev
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
 }
 
+// Developer probe (tools/shade_probe.py; -DPBRS_PROBE_SHADE builds only): wall cycles of k_shade's regions, summed per wave.
+#ifdef PBRS_PROBE_SHADE
+__device__ unsigned long long g_shade_probe[16];
+#define PBRS_SHADE_MARK(k)                                          \
+    do {                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        probe_acc[k] += now_ - probe_t;                             \
+        probe_t = now_;                                             \
+    } while (0)
+#else
+#define PBRS_SHADE_MARK(k) \
+    do {                   \
+    } while (0)
+#endif
+
 PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:224-232, BETA = 2, nf = ng = 1
     float f = 1.0f * f_pdf;
     float g = 1.0f * g_pdf;
@@ -316,6 +331,10 @@ template <uint32_t INTEG>
 __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* queue,
                                               const uint32_t* count, uint32_t n_direct, uint32_t* queue_out, uint32_t* count_out,
                                               uint32_t* nee_queue, unsigned long long* nee_shadow_count) {
+#ifdef PBRS_PROBE_SHADE
+    unsigned long long probe_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long probe_t = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = queue ? *count : n_direct;
     bool valid = i < n;
@@ -360,6 +379,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
             post = __uint_as_float(flags);
             if (!has_hit) L = L + cmul(ld3(S.env), beta) * post;  // :54, then spec_refl * f * pr.mass().weak_recip() (:37)
         }
+        PBRS_SHADE_MARK(0);  // queue + state loads, emission
         if (has_hit && !emitter_hit) {
             uint64_t rng = at(st.rng, slot);
 #ifdef PBRS_ABL_NO_RECON  // timing-only ablation build: skips the Interaction rebuild, results are wrong
@@ -372,6 +392,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
             Isect is = reconstruct_isect(S, h, o, d);
 #endif
             Bsdf bs = bsdf_new_frame(is, S.bxdfs + mat->first_bxdf, mat->n_bxdfs);
+            PBRS_SHADE_MARK(1);  // interaction rebuild + frame
 
             // uniform_sample_one_light, directlighting.rs:58-99
             uint32_t num_lights = S.n_delta + S.n_area + S.has_env;
@@ -412,6 +433,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     float lpdf;
                     ShadowRay vis;
                     area_sample_incident(Lt, is, lu, lv, li, wi, lpdf, vis);
+                    PBRS_SHADE_MARK(2);  // NEE: draws + light sample + its pdf
                     if (lpdf > 0.0f && !is_black(li)) {
                         f3 bv = bsdf_eval(bs, is.wo, wi) * pn_abs(dot(is.normal, wi));
                         float spdf = bsdf_pdf(bs, is.wo, wi);
@@ -421,6 +443,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                             v1 = vis;
                         }
                     }
+                    PBRS_SHADE_MARK(3);  // NEE term 1: BSDF eval + pdf + MIS weight
                     f3 f2, wi2;
                     ProbD pr2;
                     bsdf_sample(bs, is.wo, su, sv, f2, wi2, pr2);
@@ -449,6 +472,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     c1 = cmul(ld3(S.env), f2) * ac * wr;
                     c2 = cmul(gray(0.0f), f2) * ac * wr;  // Color::black() * f * ..., the occluded arm
                 }
+                PBRS_SHADE_MARK(4);  // NEE term 2: BSDF sample + light intersection + pdf
                 cast0 = v1.t_max >= 0.0f;
                 cast1 = v2.t_max >= 0.0f;
                 if (cast0 && cast1) {
@@ -506,6 +530,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     at(st.flags, slot) = __float_as_uint(pn_weak_recip(pr.v));
                 }
             } else {
+            PBRS_SHADE_MARK(5);  // NEE bookkeeping (cast flags, both outcomes)
             // pathintegrator.rs:46-71
             float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);
             f3 f, wi;
@@ -536,6 +561,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
             }
         }
         st_col(st.lr, st.lg, st.lb, slot, L);
+        PBRS_SHADE_MARK(6);  // bounce: BSDF sample, beta, spawn, roulette, state stores
     }
     // Stream compaction of the three outputs.  A hot queue tail serialises at ~10 ns per atomic on gfx950, so the
     // counts are first summed per block through LDS and the tails are bumped by TWO atomics per block: the
@@ -593,6 +619,11 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
             rec[3] = make_float4(add_o.x, add_o.y, add_o.z, 0.0f);
         }
     }
+#ifdef PBRS_PROBE_SHADE
+    PBRS_SHADE_MARK(7);  // compaction + queue / record writes
+    if ((threadIdx.x & 63u) == 0 && __ballot(valid) != 0 && (blockIdx.x % 61u) == 0)  // a sample of the blocks
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_shade_probe[k], probe_acc[k]);
+#endif
 }
 
 // ---- shadow ----------------------------------------------------------------------------------------------------

@@ -399,6 +399,16 @@ int collect(pbrs_ctx* c, pbrs_stats* out) {
 
 extern "C" {
 
+#ifdef PBRS_PROBE_SHADE
+// developer probe: reads and clears the k_shade region cycle sums
+int pbrs_debug_shade_probe(unsigned long long* out16) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_shade_probe), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long zero[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_shade_probe), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     if (!out) return PBRS_E_INVALID;
     *out = nullptr;
