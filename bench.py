@@ -111,12 +111,17 @@ def main():
     out_host = torch.empty((max(my_rows, 1), W, 3), dtype=torch.float32).pin_memory()
     bands = (tiling.BAND_ROWS, world, rank) if world > 1 else None
 
+    # one node: the ranks write their rows into a frame in shared memory (no data through gloo); otherwise gloo gather
+    shared = tiling.SharedFrame.create(W, H, world, rank) if world > 1 else None
+
     def step(timing=False, counters=False):
         if my_rows:
             ctx.render_device(out_dev.data_ptr(), sx, sy, depth, args.seed, tile=(0, 0, W, my_rows), bands=bands,
                               samples_per_pass=args.samples_per_pass, timing=timing, counters=counters)
         torch.cuda.synchronize()
         out_host.copy_(out_dev)
+        if shared is not None:
+            return shared.publish(out_host.numpy()[:my_rows])
         return tiling.gather_frame(out_host.numpy()[:my_rows], W, H, world, rank)
 
     def barrier():
@@ -217,6 +222,8 @@ def main():
             sample = tuple(args.cpu_sample) if args.cpu_sample else (384, 384, 4)
             result["cpu_baseline"] = cpu_baseline(args.config, depth, args.seed, sample)
         print(json.dumps(result))
+    if shared is not None:
+        shared.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -61,3 +61,57 @@ def gather_frame(share, width, height, world, rank, group=None, band_rows=BAND_R
         return assemble([b.numpy()[:heights[r]] for r, b in enumerate(bufs)], width, height, world, band_rows)
     dist.gather(mine, gather_list=None, dst=0, group=group)
     return None
+
+
+class SharedFrame:
+    """The frame buffer of a one-node job in POSIX shared memory: every rank writes its own rows in place, one barrier
+    makes the frame complete, nothing is sent.  (`gather_frame` moves 12 B per pixel through gloo's TCP loopback,
+    ≈30 ms for a 1024² frame on 8 ranks — more than half of a rank's render time at 8 GPUs; this costs a row scatter of
+    the rank's own share plus a barrier.)  All ranks must be on the node that created it: `create` falls back to None
+    when /dev/shm cannot be used, and the caller then keeps `gather_frame`."""
+
+    def __init__(self, path, width, height, world, rank, owner, band_rows=BAND_ROWS):
+        self.path, self.owner, self.world, self.rank = path, owner, world, rank
+        self.frame = np.memmap(path, dtype=np.float32, mode="r+", shape=(height, width, 3))
+        self.rows = owned_rows(height, world, rank, band_rows)
+
+    @classmethod
+    def create(cls, width, height, world, rank, group=None, band_rows=BAND_ROWS):
+        import os
+        import torch.distributed as dist
+        name = [None]
+        if rank == 0:
+            try:
+                path = f"/dev/shm/pbrs_frame_{os.getpid()}"
+                with open(path, "wb") as f:
+                    f.truncate(width * height * 3 * 4)
+                name[0] = path
+            except OSError:
+                name[0] = None
+        dist.broadcast_object_list(name, src=0, group=group)
+        ok = [name[0] is not None and os.path.exists(name[0])]  # a rank on another node does not see the file
+        oks = [None] * world
+        dist.all_gather_object(oks, ok[0], group=group)
+        if not all(oks):
+            if rank == 0 and name[0]:
+                os.unlink(name[0])
+            return None
+        return cls(name[0], width, height, world, rank, owner=(rank == 0), band_rows=band_rows)
+
+    def publish(self, share, group=None):
+        """Writes this rank's packed rows into the frame; after the barrier the frame is complete.  Returns the frame
+        (a view of the shared buffer) on rank 0, None elsewhere."""
+        import torch.distributed as dist
+        if len(self.rows):
+            self.frame[self.rows] = share
+        dist.barrier(group=group)
+        return self.frame if self.rank == 0 else None
+
+    def close(self):
+        import os
+        del self.frame
+        if self.owner:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
