@@ -117,7 +117,8 @@ typedef struct pbrs_tri_shade {
     uint32_t orig; /* index of the triangle in the input index buffer */
 } pbrs_tri_shade;
 
-/* geometry/src/bxdf.rs:263-269 flattened (textures are Solid, so `bxdfs_at` is constant per material). */
+/* geometry/src/bxdf.rs:263-269 flattened: `bxdfs_at` is constant per material when its textures are Solid; a lobe whose
+ * colour comes from another texture names it in `tex` and the colour is evaluated per hit (material/src/lib.rs). */
 enum pbrs_bxdf_kind { PBRS_BXDF_SPECULAR = 0, PBRS_BXDF_DIFFUSE = 1, PBRS_BXDF_MICROFACET = 2 };
 enum pbrs_intrusion { PBRS_REFLECTION = 0, PBRS_TRANSMISSION = 1, PBRS_HYBRID = 2 };        /* bxdf.rs:35-40  */
 enum pbrs_fresnel_kind { PBRS_FRESNEL_NOP = 0, PBRS_FRESNEL_DIELECTRIC = 1, PBRS_FRESNEL_CONDUCTOR = 2 }; /* :284-289 */
@@ -131,16 +132,32 @@ typedef struct pbrs_bxdf {
     float eta[3];         /* dielectric: eta_front, eta_back, -; conductor: eta_t rgb (eta_i = 1) */
     float alpha_y;
     float k[3];           /* conductor k rgb; Oren-Nayar: coeff_a, coeff_b, - */
-    float pad;
+    uint32_t tex;         /* 0: `albedo` is the colour; else (texture index + 1) | PBRS_BXDF_TEX_DROP_IF_BLACK */
 } pbrs_bxdf;
+/* Uber pushes a textured lobe only when the texture's value at the hit is not black (material/src/lib.rs:326-362) */
+#define PBRS_BXDF_TEX_DROP_IF_BLACK 0x80000000u
 
 #define PBRS_MAX_BXDFS 5 /* Uber, material/src/lib.rs:317-365 */
 typedef struct pbrs_material {
     float emission[3]; /* Material::emission, material/src/lib.rs:24-26, :294-296 */
     uint32_t n_bxdfs;
     uint32_t first_bxdf;
-    uint32_t pad[3];
+    uint32_t flags; /* PBRS_MATERIAL_TEXTURED: some lobe has tex != 0 */
+    uint32_t pad[2];
 } pbrs_material;
+#define PBRS_MATERIAL_TEXTURED 1u
+
+/* texture/src/lib.rs:35-223 (Solid is folded into the lobes).  PERLIN: rand_vec = tex_floats[data .. data + 768),
+ * perm_x|y|z = tex_words[perm .. perm + 768); IMAGE: texels = tex_floats[data .. data + 3 * width * height). */
+typedef struct pbrs_texture {
+    uint32_t kind; /* enum pbrs_texture_kind (pbrs_scene_spec.h) */
+    float odd[3];
+    float even[3];
+    float freq;
+    uint32_t width, height;
+    uint32_t data; /* offset into tex_floats */
+    uint32_t perm; /* offset into tex_words */
+} pbrs_texture;
 
 /* light/src/lib.rs:107-111 + light/src/sample_shape.rs:38-43 (world-space shape, area precomputed). */
 typedef struct pbrs_area_light {
@@ -183,7 +200,15 @@ typedef struct pbrs_scene_desc {
     uint32_t n_delta_lights;
     const pbrs_delta_light* delta_lights;
     float env_constant[3]; /* EnvLight::Constant, scene/src/lib.rs:12-16 */
-    uint32_t pad;
+    uint32_t env_kind;     /* enum pbrs_env_kind (pbrs_scene_spec.h) */
+    uint32_t n_textures;
+    const pbrs_texture* textures;
+    uint32_t n_tex_floats;
+    const float* tex_floats;
+    uint32_t n_tex_words;
+    const uint32_t* tex_words;
+    uint32_t env_texture;  /* PBRS_ENV_IMAGE: index into textures[] */
+    float env_scale[3];
 } pbrs_scene_desc;
 
 /* geometry/src/camera.rs:9-17 with the three `orientation * {c,a,b}` products of shoot_ray (:68-70)

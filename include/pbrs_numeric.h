@@ -107,6 +107,8 @@ PN_FN float pn_powi(float a, int b) {
     return recip ? 1.0f / r : r;
 }
 PN_FN float pn_sq(float a) { return a * a; } /* powi(2) */
+/* f32::mul_add: ONE rounding (the only fused operation on the path; everything else is compiled -ffp-contract=off) */
+PN_FN float pn_mul_add(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 /* 2^n as f32 for n in [-126, 127] */
 PN_FN float pn_exp2i(int n) { return pn_from_bits((uint32_t)(n + 127) << 23); }

@@ -46,7 +46,24 @@ typedef struct pbrs_mesh_spec {
     const uint32_t* indices; /* n_triangles * 3, as given to from_soa (NOT yet (i,k,j)-swapped) */
 } pbrs_mesh_spec;
 
-/* material/src/lib.rs — every texture is `Solid` (texture/src/lib.rs:19-33) in this tier. */
+/* texture/src/lib.rs.  `Solid` (:19-33) stays inline in the material parameters; the others are referenced by
+ * pbrs_material_spec.tex.  Perlin's tables come from the unseeded `rand::random` in the reference (:66-95): here they are
+ * part of the scene (any 256 unit vectors + three permutations of 0..255), so both sides evaluate the same noise. */
+enum pbrs_texture_kind {
+    PBRS_TEX_CHECKER = 1, /* odd / even by the sign of sin(10x) sin(10y) sin(10z)                 (:35-49)   */
+    PBRS_TEX_PERLIN = 2,  /* marble: sin(freq * z + 10 * turbulence(p)) * 0.5 + 0.5, grey          (:51-171)  */
+    PBRS_TEX_IMAGE = 3    /* nearest texel of a width x height RGB image, uv clamped to [0, 1]     (:173-223) */
+};
+typedef struct pbrs_texture_spec {
+    uint32_t kind;
+    float odd[3], even[3];    /* CHECKER */
+    float freq;               /* PERLIN */
+    uint32_t width, height;   /* IMAGE */
+    const float* data;        /* PERLIN: rand_vec, 256 * 3;  IMAGE: width * height * 3 (row-major, already in [0, 1]) */
+    const uint32_t* perm;     /* PERLIN: perm_x, perm_y, perm_z, 3 * 256 */
+} pbrs_texture_spec;
+
+/* material/src/lib.rs — colours are `Solid` unless pbrs_material_spec.tex names a texture. */
 enum pbrs_material_kind {
     PBRS_MTL_LAMBERTIAN = 0,    /* p[0..3) albedo                                            (:31-44)  */
     PBRS_MTL_METAL = 1,         /* p[0..3) eta, p[3..6) k, p[6] fuzziness                    (:45-65)  */
@@ -67,6 +84,9 @@ typedef struct pbrs_material_spec {
     uint32_t kind;
     uint32_t flags;
     float p[16];
+    /* 0 = the colour in p[]; t + 1 = textures[t].  LAMBERTIAN: tex[0] albedo (material/src/lib.rs:32-44);
+     * UBER: tex[0..4) = kd, ks, kr, kt (:303-306).  Other kinds take no textures in the reference. */
+    uint32_t tex[4];
 } pbrs_material_spec;
 
 /* tlas/src/instance.rs:12-16; transform = AffineTransform{forward, inverse} as two column-major
@@ -116,7 +136,14 @@ typedef struct pbrs_scene_spec {
     const pbrs_delta_light_spec* delta_lights;
     float env_constant[3]; /* EnvLight::Constant (black = no env light, scene/src/lib.rs:96-102) */
     pbrs_camera_spec camera;
+    uint32_t n_textures;
+    const pbrs_texture_spec* textures;
+    uint32_t env_kind;     /* enum pbrs_env_kind; CONSTANT reads env_constant */
+    uint32_t env_texture;  /* IMAGE: index into textures[] (an IMAGE texture), looked up at lat-long (u, v) (:108-114) */
+    float env_scale[3];    /* IMAGE: `scale_factor` */
 } pbrs_scene_spec;
+/* scene/src/lib.rs:20-24 EnvLight; the `Fn` arm carries one of the closures of scene/src/preset.rs:25-53 */
+enum pbrs_env_kind { PBRS_ENV_CONSTANT = 0, PBRS_ENV_IMAGE = 1, PBRS_ENV_BLUE_SKY = 2, PBRS_ENV_DARK_ROOM = 3, PBRS_ENV_DUSK = 4 };
 
 #ifdef __cplusplus
 }

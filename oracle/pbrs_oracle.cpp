@@ -27,10 +27,32 @@ std::unique_ptr<Scene> scene_from_spec(const pbrs_scene_spec& spec) {
     for (uint32_t m = 0; m < spec.n_meshes; ++m) meshes.push_back(std::shared_ptr<TriangleMesh>(mesh_from_soa(spec.meshes[m])));
     std::vector<std::shared_ptr<Shape>> shapes;
     for (uint32_t s = 0; s < spec.n_shapes; ++s) shapes.push_back(std::make_shared<Shape>(shape_from_spec(spec.shapes[s], meshes)));
+    std::vector<std::shared_ptr<Texture>> textures;
+    for (uint32_t t = 0; t < spec.n_textures; ++t) {
+        const pbrs_texture_spec& ts = spec.textures[t];
+        auto tx = std::make_shared<Texture>();
+        tx->kind = ts.kind;
+        tx->odd = Color{ts.odd[0], ts.odd[1], ts.odd[2]};
+        tx->even = Color{ts.even[0], ts.even[1], ts.even[2]};
+        tx->freq = ts.freq;
+        tx->width = ts.width;
+        tx->height = ts.height;
+        if (ts.kind == PBRS_TEX_PERLIN) {
+            for (int k = 0; k < 256; ++k) tx->rand_vec.push_back(Vec3{ts.data[3 * k], ts.data[3 * k + 1], ts.data[3 * k + 2]});
+            tx->perm_x.assign(ts.perm, ts.perm + 256);
+            tx->perm_y.assign(ts.perm + 256, ts.perm + 512);
+            tx->perm_z.assign(ts.perm + 512, ts.perm + 768);
+        } else if (ts.kind == PBRS_TEX_IMAGE) {
+            for (size_t k = 0; k < (size_t)ts.width * ts.height; ++k) tx->data.push_back(Color{ts.data[3 * k], ts.data[3 * k + 1], ts.data[3 * k + 2]});
+        }
+        textures.push_back(tx);
+    }
     std::vector<std::shared_ptr<Material>> mtls;
     for (uint32_t m = 0; m < spec.n_materials; ++m) {
         auto mt = std::make_shared<Material>();
         mt->spec = spec.materials[m];
+        for (int k = 0; k < 4; ++k)
+            if (spec.materials[m].tex[k]) mt->tex[k] = textures.at(spec.materials[m].tex[k] - 1);
         mtls.push_back(mt);
     }
     std::vector<std::unique_ptr<Instance>> instances;
@@ -67,8 +89,44 @@ std::unique_ptr<Scene> scene_from_spec(const pbrs_scene_spec& spec) {
         scene->delta_lights.push_back(light);
     }
     scene->env_constant = Color{spec.env_constant[0], spec.env_constant[1], spec.env_constant[2]};
+    scene->env_kind = spec.env_kind;
+    if (spec.env_kind == PBRS_ENV_IMAGE) scene->env_map = textures.at(spec.env_texture);
+    scene->env_scale = Color{spec.env_scale[0], spec.env_scale[1], spec.env_scale[2]};
     scene->camera = camera_from_spec(spec.camera);
     return scene;
+}
+
+// ---- scene/src/lib.rs:105-117, scene/src/preset.rs:25-53 ---------------------------------------------------------
+Color Scene::eval_env_light(const Ray& ray) const {
+    switch (env_kind) {
+        case PBRS_ENV_IMAGE: {  // lib.rs:108-114
+            float phi = pn_atan2(ray.dir.z, ray.dir.x);
+            float u = pn_fract(phi * PN_FRAC_1_PI * 0.5f + 1.0f);
+            float cos_theta = ray.dir.y / norm(ray.dir);
+            float v = pn_acos(cos_theta) / PN_PI;
+            return env_map->value(u, v, Point3{0.0f, 0.0f, 0.0f}) * env_scale;
+        }
+        case PBRS_ENV_BLUE_SKY: {  // preset.rs:25-30
+            float y = (hat(ray.dir).y + 1.0f) * 0.5f;
+            return Color{0.5f, 0.7f, 1.0f} * y + gray(1.0f) * (1.0f - y);
+        }
+        case PBRS_ENV_DARK_ROOM: {  // :32-37
+            float y = (hat(ray.dir).y + 1.0f) * 0.5f;
+            return gray(0.1f) * y + gray(0.1f) * (1.0f - y);
+        }
+        case PBRS_ENV_DUSK: {  // :39-52; Color::rgb(u8, u8, u8) = x as f32 / 255.0 (radiometry/src/color.rs)
+            Color horizon{245.0f / 255.0f, 174.0f / 255.0f, 82.0f / 255.0f};
+            Color dome{109.0f / 255.0f, 150.0f / 255.0f, 204.0f / 255.0f};
+            float tilt = pn_acos(hat(ray.dir).y);
+            if (tilt > PN_PI * 0.25f) return dome;
+            if (tilt > 0.0f) {
+                float t = tilt / (PN_PI * 0.25f);
+                return dome * t + horizon * (1.0f - t);
+            }
+            return gray(0.2f);
+        }
+        default: return env_constant;
+    }
 }
 
 // ---- src/directlighting.rs ----------------------------------------------------------------------------

@@ -175,9 +175,24 @@ struct BSDF {
 };
 BSDF bsdf_new_frame(const Interaction& isect);  // :18-31
 
+// ---- texture/src/lib.rs ------------------------------------------------------------------------
+struct Texture {
+    uint32_t kind = 0;  // pbrs_texture_kind
+    Color odd, even;                          // Checker :35-49
+    float freq = 1.0f;                        // Perlin :51-171
+    std::vector<Vec3> rand_vec;               // 256
+    std::vector<uint32_t> perm_x, perm_y, perm_z;
+    std::vector<Color> data;                  // Image :173-223
+    uint32_t width = 0, height = 0;
+    Color value(float u, float v, Point3 p) const;
+    float noise(Point3 p) const;       // :97-137
+    float turbulance(Point3 p) const;  // :139-147
+};
+
 // ---- material/src/lib.rs -----------------------------------------------------------------------
 struct Material {
     pbrs_material_spec spec;
+    std::shared_ptr<Texture> tex[4];  // nullptr = the Solid colour in spec.p
     std::vector<BXDF> bxdfs_at(const Interaction& isect) const;  // per-kind `bxdfs_at`
     Color emission() const;                                      // :24-26, :294-296
 };
@@ -252,9 +267,12 @@ struct Scene {
     std::vector<DeltaLight> delta_lights;
     std::vector<DiffuseAreaLight> area_lights;
     Color env_constant;
+    uint32_t env_kind = 0;             // pbrs_env_kind: Constant, Image, or one of the Fn closures of preset.rs:25-53
+    std::shared_ptr<Texture> env_map;  // Image
+    Color env_scale;
     Camera camera;
-    bool has_env_light() const { return !is_black(env_constant); }  // :96-103 (Constant only)
-    Color eval_env_light(const Ray&) const { return env_constant; } // :105-117
+    bool has_env_light() const { return env_kind != PBRS_ENV_CONSTANT || !is_black(env_constant); }  // :96-103
+    Color eval_env_light(const Ray& ray) const;                                                      // :105-117
 };
 std::unique_ptr<Scene> scene_from_spec(const pbrs_scene_spec& spec);
 

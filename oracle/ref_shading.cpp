@@ -522,16 +522,80 @@ void BSDF::sample(Vec3 wo_world, float u, float v, Color* f, Vec3* wi_out, Prob*
 
 // ---- material/src/lib.rs -----------------------------------------------------------------------------
 static Color c3(const float* p) { return Color{p[0], p[1], p[2]}; }
+// ---- texture/src/lib.rs ------------------------------------------------------------------------------------
+float Texture::noise(Point3 p) const {  // :97-137
+    auto split = [](float f, int* i, float* u) {
+        float fl = pn_floor(f);
+        *i = (int)fl;  // `f.floor() as i32`
+        *u = f - fl;
+    };
+    int i, j, k;
+    float u, v, w;
+    split(p.x * freq, &i, &u);
+    split(p.y * freq, &j, &v);
+    split(p.z * freq, &k, &w);
+    u = u * u * (3.0f - 2.0f * u);
+    v = v * v * (3.0f - 2.0f * v);
+    w = w * w * (3.0f - 2.0f * w);
+    Vec3 c[2][2][2];
+    for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int dk = 0; dk < 2; ++dk) {
+                uint32_t index = perm_x[(size_t)((i + di) & 255)] ^ perm_y[(size_t)((j + dj) & 255)] ^ perm_z[(size_t)((k + dk) & 255)];
+                c[di][dj][dk] = rand_vec[index];
+            }
+    float accum = 0.0f;
+    for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int dk = 0; dk < 2; ++dk) {
+                Vec3 weight_v{u - (float)di, v - (float)dj, w - (float)dk};
+                float dot_product = dot(c[di][dj][dk], weight_v);
+                accum += ((float)di * u + (float)(1 - di) * (1.0f - u)) * ((float)dj * v + (float)(1 - dj) * (1.0f - v)) *
+                         ((float)dk * w + (float)(1 - dk) * (1.0f - w)) * dot_product;
+            }
+    REF_ASSERT(accum >= -1.0f);
+    REF_ASSERT(accum <= 1.0f);
+    return accum;
+}
+float Texture::turbulance(Point3 p) const {  // :139-147
+    float acc = 0.0f;
+    for (int i = 0; i < 7; ++i) {
+        float scale = pn_powi(2.0f, i);
+        acc = acc + pn_powi(0.5f, i) * noise(Point3{p.x * scale, p.y * scale, p.z * scale});
+    }
+    return pn_abs(acc);
+}
+Color Texture::value(float u, float v, Point3 p) const {
+    switch (kind) {
+        case PBRS_TEX_CHECKER: {  // :40-49
+            float sines = pn_sin(10.0f * p.x) * pn_sin(10.0f * p.y) * pn_sin(10.0f * p.z);
+            return sines < 0.0f ? odd : even;
+        }
+        case PBRS_TEX_PERLIN:  // :150-160: a marble-like texture
+            return pn_mul_add(pn_sin(freq * p.z + 10.0f * turbulance(p)), 0.5f, 0.5f) * gray(1.0f);
+        default: {  // Image :211-223
+            float uc = pn_clamp(u, 0.0f, 1.0f), vc = pn_clamp(v, 0.0f, 1.0f);
+            // `(u * w as f32) as usize % w`: Rust's float -> int cast saturates and sends NaN to 0
+            auto to_usize = [](float x) -> uint64_t { return x != x ? 0u : (x <= 0.0f ? 0u : (x >= 1.8446744e19f ? ~0ull : (uint64_t)x)); };
+            uint64_t col = to_usize(uc * (float)width) % width;
+            uint64_t row = to_usize(vc * (float)height) % height;
+            return data[row * width + col];
+        }
+    }
+}
+
 Color Material::emission() const {  // :24-26, :294-296
     if (spec.kind == PBRS_MTL_DIFFUSE_LIGHT) return c3(spec.p);
     return black();
 }
-std::vector<BXDF> Material::bxdfs_at(const Interaction&) const {
+std::vector<BXDF> Material::bxdfs_at(const Interaction& isect) const {
     std::vector<BXDF> out;
     const float* p = spec.p;
+    // `self.kd.value(isect.uv, isect.pos)`: a Solid texture is the colour in p[]
+    auto colour = [&](int slot, const float* solid) { return tex[slot] ? tex[slot]->value(isect.u, isect.v, isect.pos) : c3(solid); };
     switch (spec.kind) {
-        case PBRS_MTL_LAMBERTIAN:  // :180-184 (Solid texture: texture/src/lib.rs:29-33)
-            out.push_back(bxdf_lambertian(c3(p)));
+        case PBRS_MTL_LAMBERTIAN:  // :180-184
+            out.push_back(bxdf_lambertian(colour(0, p)));
             break;
         case PBRS_MTL_METAL: {  // :200-206
             float alpha = roughness_to_alpha(p[6]);
@@ -564,9 +628,9 @@ std::vector<BXDF> Material::bxdfs_at(const Interaction&) const {
             float opacity = p[15], eta = p[14];
             Color transmission = gray(pn_clamp(1.0f - opacity, 0.0f, 1.0f));
             if (!is_black(transmission)) out.push_back(bxdf_transmit(transmission, 1.0f, eta));
-            Color kd = c3(p);
+            Color kd = colour(0, p);
             if (!is_black(kd)) out.push_back(bxdf_lambertian(kd));
-            Color ks = c3(p + 3);
+            Color ks = colour(1, p + 3);
             if (!is_black(ks)) {
                 float ru = p[12], rv = p[13];
                 float au = ru, av = rv;
@@ -578,11 +642,11 @@ std::vector<BXDF> Material::bxdfs_at(const Interaction&) const {
                 out.push_back(bxdf_microfacet(ks, d, fresnel_dielectric(1.0f, eta)));
             }
             if (spec.flags & PBRS_MTL_FLAG_HAS_KR) {
-                Color kr = c3(p + 6);
+                Color kr = colour(2, p + 6);
                 if (!is_black(kr)) out.push_back(bxdf_dielectric(kr, 1.0f, eta));
             }
             if (spec.flags & PBRS_MTL_FLAG_HAS_KT) {
-                Color kt = c3(p + 9);
+                Color kt = colour(3, p + 9);
                 if (!is_black(kt)) out.push_back(bxdf_transmit(kt, 1.0f, eta));
             }
             break;

@@ -36,7 +36,11 @@ class SceneDesc(C.Structure):
                 ("n_bxdfs", C.c_uint32), ("bxdfs", C.c_void_p),
                 ("n_area_lights", C.c_uint32), ("area_lights", C.c_void_p),
                 ("n_delta_lights", C.c_uint32), ("delta_lights", C.c_void_p),
-                ("env_constant", C.c_float * 3), ("pad", C.c_uint32)]
+                ("env_constant", C.c_float * 3), ("env_kind", C.c_uint32),
+                ("n_textures", C.c_uint32), ("textures", C.c_void_p),
+                ("n_tex_floats", C.c_uint32), ("tex_floats", C.c_void_p),
+                ("n_tex_words", C.c_uint32), ("tex_words", C.c_void_p),
+                ("env_texture", C.c_uint32), ("env_scale", C.c_float * 3)]
 
 
 class Camera(C.Structure):

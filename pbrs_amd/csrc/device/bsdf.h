@@ -150,10 +150,10 @@ PD f3 beckmann_sample_wh(float ax, float ay, f3 wo, float u, float v) {         
 }
 
 // ---- lobes ----------------------------------------------------------------------------------------------------------
-PD f3 bxdf_eval(const pbrs_bxdf& b, f3 wo, f3 wi) {
+// `albedo` is the lobe's colour at this hit: pbrs_bxdf::albedo, or the value of its texture (Bsdf::albedo_at)
+PD f3 bxdf_eval(const pbrs_bxdf& b, f3 albedo, f3 wo, f3 wi) {
     if (b.kind == PBRS_BXDF_SPECULAR) return gray(0.0f);  // :458-460
     if (b.kind == PBRS_BXDF_DIFFUSE) {                    // :540-559
-        f3 albedo = ld3(b.albedo);
         if (!b.oren_nayar) return albedo * PN_FRAC_1_PI;
         float sin_theta_i = sin_theta(wi), sin_theta_o = sin_theta(wo);
         float sin_phi_i, cos_phi_i, sin_phi_o, cos_phi_o;
@@ -178,7 +178,7 @@ PD f3 bxdf_eval(const pbrs_bxdf& b, f3 wo, f3 wi) {
     if (cos_theta_o == 0.0f || cos_theta_i == 0.0f || !has_wh) return gray(0.0f);
     wh = face_forward(wh, mk3(0.0f, 0.0f, 1.0f));
     f3 refl = fresnel_eval(b, dot(wi, wh));
-    return cmul(ld3(b.albedo) * beckmann_d(b.alpha_x, b.alpha_y, wh) * beckmann_g(b.alpha_x, b.alpha_y, wo, wi), refl) *
+    return cmul(albedo * beckmann_d(b.alpha_x, b.alpha_y, wh) * beckmann_g(b.alpha_x, b.alpha_y, wo, wi), refl) *
            pn_weak_recip(4.0f * cos_theta_o * cos_theta_i);
 }
 PD ProbD bxdf_prob(const pbrs_bxdf& b, f3 wo, f3 wi) {
@@ -192,12 +192,12 @@ PD ProbD bxdf_prob(const pbrs_bxdf& b, f3 wo, f3 wi) {
     if (try_hat(wo + wi, wh)) return density(beckmann_pdf(b.alpha_x, b.alpha_y, wh) / (4.0f * dot(wo, wh)));
     return density(0.0f);
 }
-PD void specular_reflect(const pbrs_bxdf& b, f3 wo, f3& wi, f3& f) {  // :427-434
+PD void specular_reflect(const pbrs_bxdf& b, f3 albedo, f3 wo, f3& wi, f3& f) {  // :427-434
     wi = mk3(-wo.x, -wo.y, wo.z);
     f3 fr_refl = fresnel_eval(b, wi.z);
-    f = cmul(fr_refl, ld3(b.albedo)) * pn_weak_recip(pn_abs(wi.z));
+    f = cmul(fr_refl, albedo) * pn_weak_recip(pn_abs(wi.z));
 }
-PD void specular_refract(const pbrs_bxdf& b, f3 wo, f3& wi, f3& f) {  // :436-454
+PD void specular_refract(const pbrs_bxdf& b, f3 albedo, f3 wo, f3& wi, f3& f) {  // :436-454
     float eta_front = b.eta[0], eta_back = b.eta[1];
     float eta_i, eta_t;
     f3 normal;
@@ -218,23 +218,23 @@ PD void specular_refract(const pbrs_bxdf& b, f3 wo, f3& wi, f3& f) {  // :436-45
     }
     wi = t;
     float f_tr = 1.0f - fresnel_refl_coeff(b, t.z);
-    f = (f_tr / pn_abs(t.z)) * ld3(b.albedo);
+    f = (f_tr / pn_abs(t.z)) * albedo;
 }
-PD void bxdf_sample(const pbrs_bxdf& b, f3 wo, float r0, float r1, f3& f, f3& wi, ProbD& pr) {
+PD void bxdf_sample(const pbrs_bxdf& b, f3 albedo, f3 wo, float r0, float r1, f3& f, f3& wi, ProbD& pr) {
     if (b.kind == PBRS_BXDF_SPECULAR) {  // :462-501
         if (b.intrusion == PBRS_REFLECTION) {
-            specular_reflect(b, wo, wi, f);
+            specular_reflect(b, albedo, wo, wi, f);
             pr = mass(1.0f);
         } else if (b.intrusion == PBRS_TRANSMISSION) {
-            specular_refract(b, wo, wi, f);
+            specular_refract(b, albedo, wo, wi, f);
             pr = mass(1.0f);
         } else {
             float refl_coeff = fresnel_refl_coeff(b, wo.z);
             if (r0 < refl_coeff) {
-                specular_reflect(b, wo, wi, f);
+                specular_reflect(b, albedo, wo, wi, f);
                 pr = mass(refl_coeff);
             } else {
-                specular_refract(b, wo, wi, f);
+                specular_refract(b, albedo, wo, wi, f);
                 pr = mass(1.0f - refl_coeff);
             }
         }
@@ -242,7 +242,7 @@ PD void bxdf_sample(const pbrs_bxdf& b, f3 wo, float r0, float r1, f3& f, f3& wi
     }
     if (b.kind == PBRS_BXDF_DIFFUSE) {  // :560-564
         wi = cos_sample_hemisphere(r0, r1);
-        f = bxdf_eval(b, wo, wi);
+        f = bxdf_eval(b, albedo, wo, wi);
         pr = bxdf_prob(b, wo, wi);
         return;
     }
@@ -255,7 +255,7 @@ PD void bxdf_sample(const pbrs_bxdf& b, f3 wo, float r0, float r1, f3& f, f3& wi
         return;
     }
     float pdf = beckmann_pdf(b.alpha_x, b.alpha_y, wh) / (4.0f * dot(wo, wh));
-    f = bxdf_eval(b, wo, w);
+    f = bxdf_eval(b, albedo, wo, w);
     wi = w;
     pr = density(pdf);
 }
@@ -265,6 +265,16 @@ struct Bsdf {
     f3 c0, c1, c2;  // frame columns: tangent, bitangent, normal
     const pbrs_bxdf* lobes;
     uint32_t n;
+    // Textured materials (material/src/lib.rs: colours from `tex.value(isect.uv, isect.pos)`): the lobes pushed for THIS
+    // hit and their colours wait in the block's LDS, entry k of a lane at [k * 256] (lobe index) and [(3 k + c) * 256]
+    // (colour), filled once per vertex by bsdf_bind_textures.  nullptr: every lobe with its own constant colour.
+    const uint32_t* hit_lobe;
+    const float* hit_albedo;
+    PD const pbrs_bxdf& lobe(uint32_t k) const { return lobes[hit_lobe ? hit_lobe[k * 256u] : k]; }
+    PD f3 albedo_at(uint32_t k) const {
+        if (hit_albedo) return mk3(hit_albedo[(3u * k) * 256u], hit_albedo[(3u * k + 1u) * 256u], hit_albedo[(3u * k + 2u) * 256u]);
+        return ld3(lobes[k].albedo);
+    }
 };
 PD Bsdf bsdf_new_frame(const Isect& is, const pbrs_bxdf* lobes, uint32_t n) {  // :18-41
     Bsdf b;
@@ -275,6 +285,8 @@ PD Bsdf bsdf_new_frame(const Isect& is, const pbrs_bxdf* lobes, uint32_t n) {  /
     b.c2 = normal;
     b.lobes = lobes;
     b.n = n;
+    b.hit_lobe = nullptr;
+    b.hit_albedo = nullptr;
     return b;
 }
 PD f3 world_to_local(const Bsdf& b, f3 w) { return hat(mk3(dot(b.c0, w), dot(b.c1, w), dot(b.c2, w))); }  // :114-118
@@ -283,9 +295,9 @@ PD f3 local_to_world(const Bsdf& b, f3 l) { return l.x * b.c0 + l.y * b.c1 + l.z
 PD bool bsdf_sample_specular(const Bsdf& b, f3 wo_world, f3& f, f3& wi_out, ProbD& pr) {
     f3 wo = world_to_local(b, wo_world);
     for (uint32_t i = 0; i < b.n; ++i) {
-        if (b.lobes[i].kind == PBRS_BXDF_SPECULAR) {
+        if (b.lobe(i).kind == PBRS_BXDF_SPECULAR) {
             f3 wi;
-            bxdf_sample(b.lobes[i], wo, 0.0f, 0.0f, f, wi, pr);
+            bxdf_sample(b.lobe(i), b.albedo_at(i), wo, 0.0f, 0.0f, f, wi, pr);
             wi_out = local_to_world(b, wi);
             return true;
         }
@@ -297,14 +309,14 @@ PD f3 bsdf_eval(const Bsdf& b, f3 wo_w, f3 wi_w) {                              
     f3 wo = world_to_local(b, wo_w);
     if (wo.z == 0.0f) return gray(0.0f);
     f3 sum = gray(0.0f);
-    for (uint32_t i = 0; i < b.n; ++i) sum = sum + bxdf_eval(b.lobes[i], wo, wi);
+    for (uint32_t i = 0; i < b.n; ++i) sum = sum + bxdf_eval(b.lobe(i), b.albedo_at(i), wo, wi);
     return sum;
 }
 PD float bsdf_pdf(const Bsdf& b, f3 wo_w, f3 wi_w) {  // :53-57 (Q7)
     f3 wi = world_to_local(b, wi_w);
     f3 wo = world_to_local(b, wo_w);
     float sum = 0.0f;
-    for (uint32_t i = 0; i < b.n; ++i) sum += dens_of(bxdf_prob(b.lobes[i], wo, wi));
+    for (uint32_t i = 0; i < b.n; ++i) sum += dens_of(bxdf_prob(b.lobe(i), wo, wi));
     return sum;
 }
 PD void bsdf_sample(const Bsdf& b, f3 wo_world, float u, float v, f3& f, f3& wi_out, ProbD& pr) {  // :59-103
@@ -320,7 +332,7 @@ PD void bsdf_sample(const Bsdf& b, f3 wo_world, float u, float v, f3& f, f3& wi_
     float remapped_u = pn_fract(u * n);
     f3 bsdf_value, wi;
     ProbD prob;
-    bxdf_sample(b.lobes[chosen], wo, v, remapped_u, bsdf_value, wi, prob);  // Q8: (v, remapped_u)
+    bxdf_sample(b.lobe(chosen), b.albedo_at(chosen), wo, v, remapped_u, bsdf_value, wi, prob);  // Q8: (v, remapped_u)
     if (prob.is_mass) {
         f = bsdf_value;
         wi_out = local_to_world(b, wi);
@@ -334,7 +346,7 @@ PD void bsdf_sample(const Bsdf& b, f3 wo_world, float u, float v, f3& f, f3& wi_
     f3 other_f = gray(0.0f);
     for (uint32_t k = 0; k < others; ++k) {
         uint32_t idx = (k == chosen) ? (b.n - 1) : k;
-        ProbD p = bxdf_prob(b.lobes[idx], wo, wi);
+        ProbD p = bxdf_prob(b.lobe(idx), wo, wi);
         if (!p.is_mass) {
             count += 1;
             other_pdf_sum += p.v;
@@ -342,7 +354,7 @@ PD void bsdf_sample(const Bsdf& b, f3 wo_world, float u, float v, f3& f, f3& wi_
     }
     for (uint32_t k = 0; k < others; ++k) {
         uint32_t idx = (k == chosen) ? (b.n - 1) : k;
-        other_f = other_f + bxdf_eval(b.lobes[idx], wo, wi);
+        other_f = other_f + bxdf_eval(b.lobe(idx), b.albedo_at(idx), wo, wi);
     }
     float overall_pdf = (prob.v + other_pdf_sum) / (float)(1 + count);
     f = bsdf_value + other_f;

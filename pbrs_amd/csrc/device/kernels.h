@@ -13,6 +13,7 @@
 // the next queue", compacted with __ballot + mbcnt prefix + one atomicAdd per wave.
 #pragma once
 #include "lights.h"
+#include "textures.h"
 #include "traverse.h"
 
 struct PathState {
@@ -327,10 +328,13 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 }
 
 // ---- shade -----------------------------------------------------------------------------------------------------
-template <uint32_t INTEG>
+template <uint32_t INTEG, bool TEX>
 __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* queue,
                                               const uint32_t* count, uint32_t n_direct, uint32_t* queue_out, uint32_t* count_out,
                                               uint32_t* nee_queue, unsigned long long* nee_shadow_count) {
+    // per-hit lobe lists of textured materials (Bsdf::hit_lobe / hit_albedo); absent from the untextured instantiation
+    __shared__ uint32_t s_hit_lobe[TEX ? PBRS_MAX_BXDFS * 256 : 1];
+    __shared__ float s_hit_albedo[TEX ? 3 * PBRS_MAX_BXDFS * 256 : 1];
 #ifdef PBRS_PROBE_SHADE
     unsigned long long probe_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long probe_t = __builtin_amdgcn_s_memtime();
@@ -365,19 +369,19 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
         float post = 1.0f;
         if (INTEG == PBRS_INTEGRATOR_PATH) {
             if (bounce == 0 || specular_bounce) {  // pathintegrator.rs:19-22
-                f3 e = has_hit ? ld3(mat->emission) : ld3(S.env);
+                f3 e = has_hit ? ld3(mat->emission) : env_eval(S, d);
                 L = L + cmul(beta, e);
             }
         } else if (bounce == 0) {
             if (!has_hit) {
-                L = ld3(S.env);  // scene.eval_env_light(ray), directlighting.rs:45
+                L = env_eval(S, d);  // scene.eval_env_light(ray), directlighting.rs:45
             } else if (!is_black(ld3(mat->emission))) {
                 L = ld3(mat->emission);  // :27-28
                 emitter_hit = true;
             }
         } else {
             post = __uint_as_float(flags);
-            if (!has_hit) L = L + cmul(ld3(S.env), beta) * post;  // :54, then spec_refl * f * pr.mass().weak_recip() (:37)
+            if (!has_hit) L = L + cmul(env_eval(S, d), beta) * post;  // :54, then spec_refl * f * pr.mass().weak_recip() (:37)
         }
         PBRS_SHADE_MARK(0);  // queue + state loads, emission
         if (has_hit && !emitter_hit) {
@@ -392,6 +396,29 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
             Isect is = reconstruct_isect(S, h, o, d);
 #endif
             Bsdf bs = bsdf_new_frame(is, S.bxdfs + mat->first_bxdf, mat->n_bxdfs);
+            if (TEX && (mat->flags & PBRS_MATERIAL_TEXTURED)) {
+                // `mtl.bxdfs_at(&hit)` with non-Solid textures (material/src/lib.rs:180-184, :317-365): evaluate each
+                // lobe's colour at (uv, pos) once, keep the lobes the material pushes for this hit
+                uint32_t* hl = s_hit_lobe + threadIdx.x;
+                float* ha = s_hit_albedo + threadIdx.x;
+                uint32_t kept = 0;
+                for (uint32_t k = 0; k < mat->n_bxdfs; ++k) {
+                    const pbrs_bxdf& lb = bs.lobes[k];
+                    f3 colour = ld3(lb.albedo);
+                    if (lb.tex) {
+                        colour = tex_value(S, (lb.tex & ~PBRS_BXDF_TEX_DROP_IF_BLACK) - 1u, is.u, is.v, is.pos);
+                        if ((lb.tex & PBRS_BXDF_TEX_DROP_IF_BLACK) && is_black(colour)) continue;
+                    }
+                    hl[kept * 256u] = k;
+                    ha[(3u * kept) * 256u] = colour.x;
+                    ha[(3u * kept + 1u) * 256u] = colour.y;
+                    ha[(3u * kept + 2u) * 256u] = colour.z;
+                    ++kept;
+                }
+                bs.n = kept;
+                bs.hit_lobe = hl;
+                bs.hit_albedo = ha;
+            }
             PBRS_SHADE_MARK(1);  // interaction rebuild + frame
 
             // uniform_sample_one_light, directlighting.rs:58-99
@@ -469,7 +496,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     v1.t_max = pn_inf();
                     float ac = pn_abs(dot(wi2, is.normal));
                     float wr = pn_weak_recip(pr2.v);
-                    c1 = cmul(ld3(S.env), f2) * ac * wr;
+                    c1 = cmul(env_eval(S, v1.d), f2) * ac * wr;  // scene.eval_env_light(incident_ray), :90-95
                     c2 = cmul(gray(0.0f), f2) * ac * wr;  // Color::black() * f * ..., the occluded arm
                 }
                 PBRS_SHADE_MARK(4);  // NEE term 2: BSDF sample + light intersection + pdf

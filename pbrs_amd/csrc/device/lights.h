@@ -32,7 +32,7 @@ PD bool light_shape_intersect(const pbrs_area_light& L, f3 o, f3 d, LightPoint& 
         case PBRS_SHAPE_DISK: {
             float t;
             if (!disk_hit_t(ld3(p), ld3(p + 3), ld3(p + 6), o, d, pn_inf(), t)) return false;
-            Isect i = disk_isect(ld3(p), ld3(p + 3), o, d, t);
+            Isect i = disk_isect(ld3(p), ld3(p + 3), ld3(p + 6), o, d, t);
             out.pos = i.pos;
             out.normal = i.normal;
             return true;

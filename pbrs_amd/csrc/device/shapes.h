@@ -37,6 +37,12 @@ struct DevScene {
     const pbrs_node* tlas_flat;
     uint32_t n_flat;
     uint32_t features;   // PBRS_FEAT_*: what the traversal kernels must be able to do for this scene
+    // texture/src/lib.rs (device/textures.h) and the environment light (scene/src/lib.rs:105-117)
+    const pbrs_texture* textures;
+    const float* tex_floats;
+    const uint32_t* tex_words;
+    uint32_t env_kind, env_texture;
+    float env_scale[3];
     uint4* world;        // PBRS_TRAVERSAL_LANES records of 3 x 16 bytes of per-lane scratch (LaneStack::world)
 };
 
@@ -73,10 +79,11 @@ PD f3 with_dpdu(f3 normal, f3 dpdu) {
     return cross(bitangent, n);
 }
 
-// What shade needs of geometry/src/interaction.rs:12-20 (uv is only read by non-Solid textures, which
-// are outside this tier: not carried).
+// What shade needs of geometry/src/interaction.rs:12-20.  uv is read by non-Solid textures only: kernels that never
+// evaluate one leave it dead and the compiler drops its computation.
 struct Isect {
     f3 pos, normal, wo, tangent;
+    float u, v;
 };
 
 // ---- Sphere (shape/src/simple.rs:207-288) ----------------------------------------------------------------
@@ -123,6 +130,8 @@ PD Isect sphere_isect(f3 center, float radius, f3 o, f3 d, float t) {  // :241-2
     i.normal = normal;  // always outward: D4, interior hits keep n·wo < 0
     i.wo = -d;
     i.tangent = with_dpdu(normal, dpdu);
+    i.u = (pn_atan2(normal.z, normal.x) + PN_PI) / (2.0f * PN_PI);  // :248-250
+    i.v = pn_acos(normal.y) / PN_PI;
     return i;
 }
 
@@ -140,7 +149,7 @@ PD bool disk_occludes(f3 center, f3 normal, f3 radial, f3 o, f3 d) {  // Q14: no
     f3 p = o + tt * d;
     return norm2(p - center) <= norm2(radial);
 }
-PD Isect disk_isect(f3 center, f3 dn, f3 o, f3 d, float t) {
+PD Isect disk_isect(f3 center, f3 dn, f3 radial, f3 o, f3 d, float t) {
     f3 p = o + t * d;
     f3 cp = p - center;
     cp = cp - dot(cp, dn) * dn;
@@ -151,6 +160,8 @@ PD Isect disk_isect(f3 center, f3 dn, f3 o, f3 d, float t) {
     i.normal = normal;
     i.wo = -d;
     i.tangent = with_dpdu(normal, tan);
+    i.u = pn_fract(pn_atan2(dot(cross(radial, cp), normal), dot(radial, cp)) * PN_FRAC_1_PI + 1.0f);  // :319-321
+    i.v = norm(cp) / norm(radial);
     return i;
 }
 
@@ -189,6 +200,8 @@ PD Isect quad_isect(f3 origin, f3 su, f3 sv, f3 o, f3 d) {
     i.normal = hat(normal);
     i.wo = -d;
     i.tangent = with_dpdu(i.normal, su);
+    i.u = u;
+    i.v = v;
     return i;
 }
 
@@ -243,6 +256,8 @@ PD Isect cuboid_isect(f3 bmin, f3 bmax, f3 o, f3 d) {
     i.normal = normal;
     i.wo = -d;
     i.tangent = with_dpdu(normal, tan);
+    i.u = 0.5f;  // :409
+    i.v = 0.5f;
     return i;
 }
 
@@ -420,7 +435,7 @@ PD Isect reconstruct_isect(const DevScene& S, const Hit& h, f3 o, f3 d) {
         }
         case PBRS_SHAPE_DISK: {
             const float* p = S.shapes[in.shape_index].p;
-            li = disk_isect(ld3(p), ld3(p + 3), oo, od, h.t);
+            li = disk_isect(ld3(p), ld3(p + 3), ld3(p + 6), oo, od, h.t);
             break;
         }
         case PBRS_SHAPE_TRIANGLE: {  // simple.rs:425-427
@@ -432,6 +447,8 @@ PD Isect reconstruct_isect(const DevScene& S, const Hit& h, f3 o, f3 d) {
             li.normal = th.normal;
             li.wo = -od;
             li.tangent = with_dpdu(th.normal, p1 - p0);
+            li.u = th.b1;  // simple.rs:470-474: uv = (b1, b2)
+            li.v = th.b2;
             break;
         }
         default: {
@@ -445,6 +462,12 @@ PD Isect reconstruct_isect(const DevScene& S, const Hit& h, f3 o, f3 d) {
             li.normal = n;
             li.wo = -od;
             li.tangent = with_dpdu(n, dpdu);
+            {  // blas.rs:176-177: uv = barycentric_lerp of the vertex uvs (float.rs:37-50, scalar form)
+                const pbrs_tri_shade& ts = S.ts[h.prim];
+                const float b0 = 1.0f - th.b1 - th.b2, b1 = th.b1;  // blas.rs:166: (1 - u - v, u, v) of the geometric hit
+                li.u = (ts.uv0[0] - ts.uv2[0]) * b0 + (ts.uv1[0] - ts.uv2[0]) * b1 + ts.uv2[0];
+                li.v = (ts.uv0[1] - ts.uv2[1]) * b0 + (ts.uv1[1] - ts.uv2[1]) * b1 + ts.uv2[1];
+            }
             break;
         }
     }
@@ -453,5 +476,7 @@ PD Isect reconstruct_isect(const DevScene& S, const Hit& h, f3 o, f3 d) {
     w.wo = xf_apply(in.fwd, li.wo, 0.0f);
     w.normal = xf_normal(in.inv, li.normal);
     w.tangent = with_dpdu(w.normal, xf_apply(in.fwd, li.tangent, 0.0f));
+    w.u = li.u;  // transform.rs:309-320 keeps uv
+    w.v = li.v;
     return w;
 }

@@ -334,8 +334,16 @@ void flatten_material(const pbrs_material_spec& m, pbrs_material* out, std::vect
     out->first_bxdf = (uint32_t)bx.size();
     const float* p = m.p;
     const float white[3] = {1.0f, 1.0f, 1.0f};
+    // a lobe whose colour is a non-Solid texture: evaluated per hit on the device (pbrs_bxdf::tex)
+    auto textured = [&](pbrs_bxdf b, uint32_t tex, bool drop_if_black) {
+        b.tex = tex | (drop_if_black ? PBRS_BXDF_TEX_DROP_IF_BLACK : 0u);
+        out->flags |= PBRS_MATERIAL_TEXTURED;
+        return b;
+    };
     switch (m.kind) {
-        case PBRS_MTL_LAMBERTIAN: bx.push_back(bx_lambert(p)); break;  // :180-184
+        case PBRS_MTL_LAMBERTIAN:  // :180-184
+            bx.push_back(m.tex[0] ? textured(bx_lambert(p), m.tex[0], false) : bx_lambert(p));
+            break;
         case PBRS_MTL_METAL: {                                          // :200-206
             float alpha = roughness_to_alpha(p[6]);
             bx.push_back(bx_microfacet(white, alpha, alpha, PBRS_FRESNEL_CONDUCTOR, p, p + 3));
@@ -362,18 +370,28 @@ void flatten_material(const pbrs_material_spec& m, pbrs_material* out, std::vect
             float tr = pn_clamp(1.0f - opacity, 0.0f, 1.0f);
             float transmission[3] = {tr, tr, tr};
             if (!black3(transmission)) bx.push_back(bx_specular(transmission, PBRS_TRANSMISSION, PBRS_FRESNEL_DIELECTRIC, 1.0f, eta));
-            if (!black3(p)) bx.push_back(bx_lambert(p));
-            if (!black3(p + 3)) {
+            if (m.tex[0]) bx.push_back(textured(bx_lambert(p), m.tex[0], true));
+            else if (!black3(p)) bx.push_back(bx_lambert(p));
+            if (m.tex[1] || !black3(p + 3)) {
                 float au = p[12], av = p[13];
                 if (m.flags & PBRS_MTL_FLAG_REMAP_ROUGHNESS) {
                     au = roughness_to_alpha(p[12]);
                     av = roughness_to_alpha(p[13]);
                 }
                 float etas[3] = {1.0f, eta, 0.0f};
-                bx.push_back(bx_microfacet(p + 3, au, av, PBRS_FRESNEL_DIELECTRIC, etas, nullptr));
+                pbrs_bxdf b = bx_microfacet(p + 3, au, av, PBRS_FRESNEL_DIELECTRIC, etas, nullptr);
+                bx.push_back(m.tex[1] ? textured(b, m.tex[1], true) : b);
             }
-            if ((m.flags & PBRS_MTL_FLAG_HAS_KR) && !black3(p + 6)) bx.push_back(bx_specular(p + 6, PBRS_HYBRID, PBRS_FRESNEL_DIELECTRIC, 1.0f, eta));
-            if ((m.flags & PBRS_MTL_FLAG_HAS_KT) && !black3(p + 9)) bx.push_back(bx_specular(p + 9, PBRS_TRANSMISSION, PBRS_FRESNEL_DIELECTRIC, 1.0f, eta));
+            if (m.flags & PBRS_MTL_FLAG_HAS_KR) {
+                pbrs_bxdf b = bx_specular(p + 6, PBRS_HYBRID, PBRS_FRESNEL_DIELECTRIC, 1.0f, eta);
+                if (m.tex[2]) bx.push_back(textured(b, m.tex[2], true));
+                else if (!black3(p + 6)) bx.push_back(b);
+            }
+            if (m.flags & PBRS_MTL_FLAG_HAS_KT) {
+                pbrs_bxdf b = bx_specular(p + 9, PBRS_TRANSMISSION, PBRS_FRESNEL_DIELECTRIC, 1.0f, eta);
+                if (m.tex[3]) bx.push_back(textured(b, m.tex[3], true));
+                else if (!black3(p + 9)) bx.push_back(b);
+            }
             break;
         }
         case PBRS_MTL_SUBSTRATE:  // :393-420 — degenerates to Lambert (Q18)
@@ -397,6 +415,9 @@ struct pbrs_host_scene {
     std::vector<pbrs_bxdf> bxdfs;
     std::vector<pbrs_area_light> area_lights;
     std::vector<pbrs_delta_light> delta_lights;
+    std::vector<pbrs_texture> textures;
+    std::vector<float> tex_floats;
+    std::vector<uint32_t> tex_words;
     pbrs_scene_desc desc;
     pbrs_camera camera;
     uint32_t stack_depth;
@@ -564,8 +585,54 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
             hs->tri_shade.push_back(pbrs_tri_shade{});
         }
     }
+    // -- textures (texture/src/lib.rs): tables and texels pooled into two flat arrays
+    for (uint32_t t = 0; t < spec->n_textures; ++t) {
+        const pbrs_texture_spec& ts = spec->textures[t];
+        pbrs_texture pt{};
+        pt.kind = ts.kind;
+        set3(pt.odd, ts.odd);
+        set3(pt.even, ts.even);
+        pt.freq = ts.freq;
+        pt.width = ts.width;
+        pt.height = ts.height;
+        pt.data = (uint32_t)hs->tex_floats.size();
+        pt.perm = (uint32_t)hs->tex_words.size();
+        if (ts.kind == PBRS_TEX_PERLIN) {
+            if (!ts.data || !ts.perm) {
+                g_error = "perlin texture without tables";
+                return PBRS_E_INVALID;
+            }
+            for (uint32_t k = 0; k < 768; ++k)
+                if (ts.perm[k] > 255u) {
+                    g_error = "perlin permutation entry above 255";
+                    return PBRS_E_INVALID;
+                }
+            hs->tex_floats.insert(hs->tex_floats.end(), ts.data, ts.data + 768);
+            hs->tex_words.insert(hs->tex_words.end(), ts.perm, ts.perm + 768);
+        } else if (ts.kind == PBRS_TEX_IMAGE) {
+            if (!ts.data || ts.width == 0 || ts.height == 0) {
+                g_error = "image texture without texels";
+                return PBRS_E_INVALID;
+            }
+            hs->tex_floats.insert(hs->tex_floats.end(), ts.data, ts.data + 3 * (size_t)ts.width * ts.height);
+        } else if (ts.kind != PBRS_TEX_CHECKER) {
+            g_error = "unknown texture kind";
+            return PBRS_E_INVALID;
+        }
+        hs->textures.push_back(pt);
+    }
+    if (spec->env_kind > PBRS_ENV_DUSK ||
+        (spec->env_kind == PBRS_ENV_IMAGE && (spec->env_texture >= spec->n_textures || spec->textures[spec->env_texture].kind != PBRS_TEX_IMAGE))) {
+        g_error = "bad environment light";
+        return PBRS_E_INVALID;
+    }
     // -- materials
     for (uint32_t m = 0; m < spec->n_materials; ++m) {
+        for (int k = 0; k < 4; ++k)
+            if (spec->materials[m].tex[k] > spec->n_textures) {
+                g_error = "material references a missing texture";
+                return PBRS_E_INVALID;
+            }
         pbrs_material pm;
         flatten_material(spec->materials[m], &pm, hs->bxdfs);
         if (pm.n_bxdfs > PBRS_MAX_BXDFS) {
@@ -687,6 +754,12 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
     d.n_area_lights = (uint32_t)hs->area_lights.size(); d.area_lights = hs->area_lights.data();
     d.n_delta_lights = (uint32_t)hs->delta_lights.size(); d.delta_lights = hs->delta_lights.data();
     set3(d.env_constant, spec->env_constant);
+    d.env_kind = spec->env_kind;
+    d.env_texture = spec->env_texture;
+    set3(d.env_scale, spec->env_scale);
+    d.n_textures = (uint32_t)hs->textures.size(); d.textures = hs->textures.data();
+    d.n_tex_floats = (uint32_t)hs->tex_floats.size(); d.tex_floats = hs->tex_floats.data();
+    d.n_tex_words = (uint32_t)hs->tex_words.size(); d.tex_words = hs->tex_words.data();
     hs->stack_depth = troot.second + max_blas_height;
     *out = hs.release();
     return PBRS_OK;

@@ -62,6 +62,7 @@ struct pbrs_ctx {
     std::vector<hipEvent_t> total_ev;  // 2
     pbrs_stats pending{};
     bool pending_counters = false, pending_times = false;
+    bool textured = false;  // the uploaded scene evaluates non-Solid textures: k_shade<.., true>
     uint64_t pending_closest = 0;
 };
 
@@ -311,12 +312,20 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         launch_extend(c, stats, pgrid, lds, qin, act + b, N, xhead + b * kHeadWords);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        if (rc.integrator == PBRS_INTEGRATOR_DIRECT)
-            hipLaunchKernelGGL(k_shade<PBRS_INTEGRATOR_DIRECT>, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N,
-                               q[(b + 1) & 1], act + b + 1, neeq, ns + b);
-        else
-            hipLaunchKernelGGL(k_shade<PBRS_INTEGRATOR_PATH>, dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N,
-                               q[(b + 1) & 1], act + b + 1, neeq, ns + b);
+        {
+#define PBRS_LAUNCH_SHADE(I, T)                                                                                                  \
+    hipLaunchKernelGGL((k_shade<I, T>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], \
+                       act + b + 1, neeq, ns + b)
+            const bool direct = rc.integrator == PBRS_INTEGRATOR_DIRECT;
+            if (c->textured) {  // some material evaluates a non-Solid texture per hit
+                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true);
+                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true);
+            } else {
+                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, false);
+                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false);
+            }
+#undef PBRS_LAUNCH_SHADE
+        }
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
         launch_shadow(c, stats, pgrid, lds, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords);
@@ -499,6 +508,28 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         const pbrs_material& m = d->materials[i];
         if (m.n_bxdfs > PBRS_MAX_BXDFS || (uint64_t)m.first_bxdf + m.n_bxdfs > d->n_bxdfs) return fail(c, PBRS_E_INVALID, "material lobes out of range");
     }
+    bool textured = false;
+    for (uint32_t i = 0; i < d->n_bxdfs; ++i) {
+        const uint32_t t = d->bxdfs[i].tex & ~PBRS_BXDF_TEX_DROP_IF_BLACK;
+        if (t > d->n_textures) return fail(c, PBRS_E_INVALID, "lobe texture out of range");
+        textured = textured || t != 0;
+    }
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const pbrs_texture& t = d->textures[i];
+        if (t.kind == PBRS_TEX_PERLIN) {
+            if ((uint64_t)t.data + 768 > d->n_tex_floats || (uint64_t)t.perm + 768 > d->n_tex_words) return fail(c, PBRS_E_INVALID, "perlin tables out of range");
+            for (uint32_t k = 0; k < 768; ++k)
+                if (d->tex_words[t.perm + k] > 255u) return fail(c, PBRS_E_INVALID, "perlin permutation entry above 255");
+        } else if (t.kind == PBRS_TEX_IMAGE) {
+            if (t.width == 0 || t.height == 0 || (uint64_t)t.data + 3ull * t.width * t.height > d->n_tex_floats)
+                return fail(c, PBRS_E_INVALID, "image texels out of range");
+        } else if (t.kind != PBRS_TEX_CHECKER) {
+            return fail(c, PBRS_E_INVALID, "unknown texture kind");
+        }
+    }
+    if (d->env_kind > PBRS_ENV_DUSK) return fail(c, PBRS_E_INVALID, "unknown environment kind");
+    if (d->env_kind == PBRS_ENV_IMAGE && (d->env_texture >= d->n_textures || d->textures[d->env_texture].kind != PBRS_TEX_IMAGE))
+        return fail(c, PBRS_E_INVALID, "environment map is not an image texture");
     for (uint32_t i = 0; i < d->n_area_lights; ++i) {
         uint32_t k = d->area_lights[i].shape_kind;
         if (!(k == PBRS_SHAPE_SPHERE || k == PBRS_SHAPE_DISK || k == PBRS_SHAPE_TRIANGLE || k == PBRS_SHAPE_QUAD))
@@ -524,9 +555,15 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     if ((rc = upload(c, d->delta_lights, d->n_delta_lights, &S.dlights))) return rc;
     S.n_area = d->n_area_lights;
     S.n_delta = d->n_delta_lights;
+    if ((rc = upload(c, d->textures, d->n_textures, &S.textures))) return rc;
+    if ((rc = upload(c, d->tex_floats, d->n_tex_floats, &S.tex_floats))) return rc;
+    if ((rc = upload(c, d->tex_words, d->n_tex_words, &S.tex_words))) return rc;
+    S.env_kind = d->env_kind;
+    S.env_texture = d->env_texture;
+    std::memcpy(S.env_scale, d->env_scale, sizeof S.env_scale);
     std::memcpy(S.env, d->env_constant, sizeof S.env);
     // Scene::has_env_light for EnvLight::Constant (scene/src/lib.rs:96-102): !c.is_black()
-    S.has_env = !(S.env[0] <= 0.0f && S.env[1] <= 0.0f && S.env[2] <= 0.0f) ? 1u : 0u;
+    S.has_env = (d->env_kind != PBRS_ENV_CONSTANT || !(S.env[0] <= 0.0f && S.env[1] <= 0.0f && S.env[2] <= 0.0f)) ? 1u : 0u;
     // The f64-reciprocal box test (device/traverse.h) is exact when every node coordinate b is finite,
     // |b| <= 2^40 and (b == 0 or |b| >= 2^-20); otherwise every lane uses the literal divisions.
     {
@@ -560,6 +597,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         }
     }
     c->S = S;
+    c->textured = textured;
     c->stack_depth = depth;
     c->has_scene = true;
     size_t lds = lds_bytes(c);

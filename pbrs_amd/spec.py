@@ -14,6 +14,8 @@ SHAPE_SPHERE, SHAPE_QUAD, SHAPE_CUBOID, SHAPE_DISK, SHAPE_TRIANGLE, SHAPE_MESH =
  MTL_SUBSTRATE) = range(9)
 MTL_FLAG_REMAP_ROUGHNESS, MTL_FLAG_HAS_KR, MTL_FLAG_HAS_KT = 1, 2, 4
 DELTA_POINT, DELTA_DISTANT = 0, 1
+TEX_CHECKER, TEX_PERLIN, TEX_IMAGE = 1, 2, 3
+ENV_CONSTANT, ENV_IMAGE, ENV_BLUE_SKY, ENV_DARK_ROOM, ENV_DUSK = range(5)
 
 f32 = np.float32
 
@@ -27,8 +29,13 @@ class MeshSpec(C.Structure):
                 ("normals", C.POINTER(C.c_float)), ("uvs", C.POINTER(C.c_float)), ("indices", C.POINTER(C.c_uint32))]
 
 
+class TextureSpec(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("odd", C.c_float * 3), ("even", C.c_float * 3), ("freq", C.c_float),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("data", C.POINTER(C.c_float)), ("perm", C.POINTER(C.c_uint32))]
+
+
 class MaterialSpec(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("flags", C.c_uint32), ("p", C.c_float * 16)]
+    _fields_ = [("kind", C.c_uint32), ("flags", C.c_uint32), ("p", C.c_float * 16), ("tex", C.c_uint32 * 4)]
 
 
 class InstanceSpec(C.Structure):
@@ -55,7 +62,9 @@ class SceneSpec(C.Structure):
                 ("n_instances", C.c_uint32), ("instances", C.POINTER(InstanceSpec)),
                 ("n_area_lights", C.c_uint32), ("area_lights", C.POINTER(AreaLightSpec)),
                 ("n_delta_lights", C.c_uint32), ("delta_lights", C.POINTER(DeltaLightSpec)),
-                ("env_constant", C.c_float * 3), ("camera", CameraSpec)]
+                ("env_constant", C.c_float * 3), ("camera", CameraSpec),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(TextureSpec)),
+                ("env_kind", C.c_uint32), ("env_texture", C.c_uint32), ("env_scale", C.c_float * 3)]
 
 
 # ---- AffineTransform (geometry/src/transform.rs:133-194) in f32, column-major Mat4 -----------------
@@ -134,6 +143,8 @@ class SceneBuilder:
         self.area_lights = []
         self.delta_lights = []
         self.env = (0.0, 0.0, 0.0)
+        self.env_kind, self.env_texture, self.env_scale = ENV_CONSTANT, 0, (1.0, 1.0, 1.0)
+        self.textures = []  # (TextureSpec, arrays kept alive)
         self.camera = None
         self._keep = []
 
@@ -174,17 +185,79 @@ class SceneBuilder:
         self.meshes.append((positions, normals, uvs, indices))
         return self._shape(SHAPE_MESH, mesh=len(self.meshes) - 1)
 
+    # -- textures (texture/src/lib.rs); returned handles go where a colour is expected in lambertian() / uber()
+    class Tex(int):
+        """Index of a texture in the scene."""
+
+    def _texture(self, t, *keep):
+        self.textures.append(t)
+        self._keep.extend(keep)
+        return SceneBuilder.Tex(len(self.textures) - 1)
+
+    def checker(self, odd, even):
+        t = TextureSpec()
+        t.kind = TEX_CHECKER
+        for i in range(3):
+            t.odd[i], t.even[i] = float(f32(odd[i])), float(f32(even[i]))
+        return self._texture(t)
+
+    def perlin(self, freq=1.0, seed=1):
+        """Perlin::with_freq (texture/src/lib.rs:66-95) with tables drawn from a seeded stream instead of `rand::random`:
+        256 uniform unit vectors (uniform_random_sphere, :6-13) and three swap-shuffled permutations (:85-95)."""
+        rs = np.random.RandomState(seed)
+        u, v = rs.rand(256).astype(f32), rs.rand(256).astype(f32)
+        theta = (f32(2.0 * np.pi) * u).astype(f32)
+        cos_phi = (f32(2.0) * v - f32(1.0)).astype(f32)
+        sin_phi = np.sqrt(np.maximum(f32(1.0) - cos_phi * cos_phi, f32(0.0))).astype(f32)
+        vec = np.ascontiguousarray(np.stack([sin_phi * np.sin(theta), sin_phi * np.cos(theta), cos_phi], axis=1), dtype=f32)
+        perm = np.empty((3, 256), dtype=np.uint32)
+        for a in range(3):
+            pm = np.arange(256, dtype=np.uint32)
+            for i in range(256):
+                j = int(rs.randint(0, 256))
+                pm[i], pm[j] = pm[j], pm[i]
+            perm[a] = pm
+        t = TextureSpec()
+        t.kind, t.freq = TEX_PERLIN, float(f32(freq))
+        t.data = vec.ctypes.data_as(C.POINTER(C.c_float))
+        t.perm = perm.ctypes.data_as(C.POINTER(C.c_uint32))
+        return self._texture(t, vec, perm)
+
+    def image(self, rgb):
+        """Image texture from an (h, w, 3) array of colours in [0, 1] (`Color::rgb(u8..)` already applied, :199-203)."""
+        rgb = np.ascontiguousarray(rgb, dtype=f32)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        t = TextureSpec()
+        t.kind, t.height, t.width = TEX_IMAGE, rgb.shape[0], rgb.shape[1]
+        t.data = rgb.ctypes.data_as(C.POINTER(C.c_float))
+        return self._texture(t, rgb)
+
+    def env_image(self, tex, scale=(1.0, 1.0, 1.0)):
+        self.env_kind, self.env_texture, self.env_scale = ENV_IMAGE, int(tex), tuple(scale)
+
+    def env_sky(self, kind):
+        """kind: ENV_BLUE_SKY / ENV_DARK_ROOM / ENV_DUSK (scene/src/preset.rs:25-53)."""
+        self.env_kind = kind
+
     # -- materials
-    def material(self, kind, p, flags=0):
+    def material(self, kind, p, flags=0, tex=()):
         m = MaterialSpec()
         m.kind, m.flags = kind, flags
         for i, v in enumerate(p):
             m.p[i] = float(f32(v))
+        for i, t in enumerate(tex):
+            m.tex[i] = 0 if t is None else int(t) + 1
         self.materials.append(m)
         return len(self.materials) - 1
 
+    @staticmethod
+    def _colour_or_tex(c):
+        """(constant colour, texture handle or None) for a parameter that may be either."""
+        return ((0.0, 0.0, 0.0), c) if isinstance(c, SceneBuilder.Tex) else (tuple(c), None)
+
     def lambertian(self, albedo):
-        return self.material(MTL_LAMBERTIAN, albedo)
+        c, t = self._colour_or_tex(albedo)
+        return self.material(MTL_LAMBERTIAN, c, tex=(t,))
 
     def metal(self, eta, k, fuzziness):
         return self.material(MTL_METAL, list(eta) + list(k) + [fuzziness])
@@ -208,8 +281,9 @@ class SceneBuilder:
     def uber(self, kd, ks, kr=None, kt=None, rough=(0.1, 0.1), eta=1.5, opacity=1.0, remap_roughness=True):
         flags = (MTL_FLAG_REMAP_ROUGHNESS if remap_roughness else 0) | (MTL_FLAG_HAS_KR if kr is not None else 0) | (
             MTL_FLAG_HAS_KT if kt is not None else 0)
-        p = list(kd) + list(ks) + list(kr or (0, 0, 0)) + list(kt or (0, 0, 0)) + list(rough) + [eta, opacity]
-        return self.material(MTL_UBER, p, flags)
+        cols, texs = zip(*(self._colour_or_tex(c if c is not None else (0, 0, 0)) for c in (kd, ks, kr, kt)))
+        p = [x for c in cols for x in c] + list(rough) + [eta, opacity]
+        return self.material(MTL_UBER, p, flags, tex=texs)
 
     def substrate(self, kd, ks):
         return self.material(MTL_SUBSTRATE, list(kd) + list(ks))
@@ -291,4 +365,8 @@ class SceneBuilder:
             spec.env_constant[i] = float(f32(self.env[i]))
         assert self.camera is not None, "camera not set"
         spec.camera = self.camera
+        spec.n_textures, spec.textures = len(self.textures), arr(self.textures, TextureSpec)
+        spec.env_kind, spec.env_texture = self.env_kind, self.env_texture
+        for i in range(3):
+            spec.env_scale[i] = float(f32(self.env_scale[i]))
         return spec
