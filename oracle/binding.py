@@ -53,6 +53,8 @@ def lib():
         L.oracle_tlas_height.restype = C.c_uint32
         L.oracle_tlas_height.argtypes = [C.c_void_p]
         L.oracle_render_tile.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.oracle_texture_value.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_env_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.oracle_render_tile_integrator.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.oracle_trace_sample.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_uint64, C.c_void_p]
         L.oracle_intersect_rays.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
@@ -120,6 +122,13 @@ class OracleScene:
         assert rc == 0
         return out, st.as_dict()
 
+    def env_eval(self, dirs):
+        """Scene::eval_env_light for ray directions (n, 3)."""
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+        out = np.empty_like(dirs)
+        lib().oracle_env_eval(self._h, len(dirs), dirs.ctypes.data, out.ctypes.data)
+        return out
+
     def trace_sample(self, row, col, sample, strata_x, strata_y, depth, seed):
         tr = PathTrace()
         lib().oracle_trace_sample(self._h, row, col, sample, strata_x, strata_y, depth, seed, C.addressof(tr))
@@ -147,3 +156,12 @@ class OracleScene:
         d = st.as_dict()
         d["tie_mask"] = ties.astype(bool)
         return hits, occ, d
+
+
+def texture_value(texture_spec, uv, pos):
+    """Texture::value(uv, p) of one pbrs_texture_spec for n (uv, p) pairs -> (n, 3) colours, panics reached."""
+    uv = np.ascontiguousarray(uv, dtype=np.float32)
+    pos = np.ascontiguousarray(pos, dtype=np.float32)
+    out = np.empty((len(uv), 3), dtype=np.float32)
+    panics = lib().oracle_texture_value(C.addressof(texture_spec), len(uv), uv.ctypes.data, pos.ctypes.data, out.ctypes.data)
+    return out, panics

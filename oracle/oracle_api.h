@@ -64,6 +64,9 @@ int oracle_intersect_rays(const oracle_scene*, uint32_t n, const float* origins,
                           oracle_hit_record* hits_out, uint8_t* occluded_out, oracle_stats* stats_out, uint8_t* tie_out);
 int oracle_camera_rays(const oracle_scene*, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t sample_index, uint32_t strata_x,
                        uint32_t strata_y, uint64_t seed, float* origins, float* dirs);
+/* texture/src/lib.rs `Texture::value(uv, p)` for n (uv, p) pairs; scene/src/lib.rs:105-117 for n ray directions. */
+int oracle_texture_value(const pbrs_texture_spec* tex, uint32_t n, const float* uv, const float* pos, float* rgb_out);
+int oracle_env_eval(const oracle_scene*, uint32_t n, const float* dirs, float* rgb_out);
 int oracle_numeric_eval(uint32_t fn, uint32_t n, const float* x, const float* y, float* out);
 int oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
 

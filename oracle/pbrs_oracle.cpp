@@ -542,6 +542,57 @@ int oracle_camera_rays(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_
 }
 
 // The f32 numeric contract, for ulp checks against libm and bitwise checks against gfx950.
+int oracle_texture_value(const pbrs_texture_spec* ts, uint32_t n, const float* uv, const float* pos, float* rgb_out) {
+    pbrs_scene_spec spec{};
+    spec.n_textures = 1;
+    spec.textures = ts;
+    pbrs_camera_spec cam{};
+    cam.width = cam.height = 1;
+    cam.fov_y_rad = 1.0f;
+    cam.target[2] = 1.0f;
+    cam.up[1] = 1.0f;
+    spec.camera = cam;
+    // only the texture table is needed: build it the way scene_from_spec does
+    Texture tx;
+    tx.kind = ts->kind;
+    tx.odd = Color{ts->odd[0], ts->odd[1], ts->odd[2]};
+    tx.even = Color{ts->even[0], ts->even[1], ts->even[2]};
+    tx.freq = ts->freq;
+    tx.width = ts->width;
+    tx.height = ts->height;
+    if (ts->kind == PBRS_TEX_PERLIN) {
+        for (int k = 0; k < 256; ++k) tx.rand_vec.push_back(Vec3{ts->data[3 * k], ts->data[3 * k + 1], ts->data[3 * k + 2]});
+        tx.perm_x.assign(ts->perm, ts->perm + 256);
+        tx.perm_y.assign(ts->perm + 256, ts->perm + 512);
+        tx.perm_z.assign(ts->perm + 512, ts->perm + 768);
+    } else if (ts->kind == PBRS_TEX_IMAGE) {
+        for (size_t k = 0; k < (size_t)ts->width * ts->height; ++k) tx.data.push_back(Color{ts->data[3 * k], ts->data[3 * k + 1], ts->data[3 * k + 2]});
+    }
+    Diag diag;
+    g_diag = &diag;
+    for (uint32_t i = 0; i < n; ++i) {
+        Color c = tx.value(uv[2 * i], uv[2 * i + 1], Point3{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]});
+        rgb_out[3 * i] = c.r;
+        rgb_out[3 * i + 1] = c.g;
+        rgb_out[3 * i + 2] = c.b;
+    }
+    g_diag = nullptr;
+    return (int)diag.panics;
+}
+int oracle_env_eval(const oracle_scene* os, uint32_t n, const float* dirs, float* rgb_out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r{};
+        r.origin = Point3{0.0f, 0.0f, 0.0f};
+        r.dir = Vec3{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+        r.t_max = pn_inf();
+        Color c = os->scene->eval_env_light(r);
+        rgb_out[3 * i] = c.r;
+        rgb_out[3 * i + 1] = c.g;
+        rgb_out[3 * i + 2] = c.b;
+    }
+    return 0;
+}
+
 int oracle_numeric_eval(uint32_t fn, uint32_t n, const float* x, const float* y, float* out) {
     for (uint32_t i = 0; i < n; ++i) {
         float a = x[i], b = y ? y[i] : 0.0f, r;
