@@ -171,7 +171,7 @@ size_t lds_bytes(const pbrs_ctx* c) {
     return b;
 }
 
-uint32_t auto_samples_per_pass(const pbrs_render_params* p);
+uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p);
 
 int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p) {
     if (!cam || !p) return fail(c, PBRS_E_INVALID, "null camera or params");
@@ -190,7 +190,7 @@ int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* 
     if (p->integrator > PBRS_INTEGRATOR_DIRECT) return fail(c, PBRS_E_INVALID, "unknown integrator");
     if ((uint64_t)p->w * p->h > (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile above 2^28 pixels");
     // queue entries keep two flag bits next to the slot index
-    if ((uint64_t)p->w * p->h * auto_samples_per_pass(p) >= (1ull << 30)) return fail(c, PBRS_E_LIMIT, "tile x samples_per_pass above 2^30 paths");
+    if ((uint64_t)p->w * p->h * auto_samples_per_pass(c, p) >= (1ull << 30)) return fail(c, PBRS_E_LIMIT, "tile x samples_per_pass above 2^30 paths");
     return PBRS_OK;
 }
 
@@ -228,14 +228,23 @@ RenderConst make_const(const pbrs_camera* cam, const pbrs_render_params* p) {
     return rc;
 }
 
-uint32_t auto_samples_per_pass(const pbrs_render_params* p) {
+uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
     uint64_t P = (uint64_t)p->w * p->h, spp = (uint64_t)p->strata_x * p->strata_y;
     uint64_t k = p->samples_per_pass;
     if (k == 0) {
-        // ~32M paths in flight (~7 GB of the 288 GB HBM for state + queues).  Every bounce is a handful of launches
-        // and a persistent traversal kernel ends with the latency of its longest walks (hundreds of dependent node
-        // fetches on a deep BLAS): the fewer, larger launches a frame is cut into, the less of it is spent draining.
-        const uint64_t target = 32ull << 20;
+        // ~128M paths in flight (~36 GB of the 288 GB HBM for state, queues and shadow-ray records), less when that would
+        // exceed a quarter of the memory currently free.  Every bounce is a handful of launches and a persistent traversal
+        // kernel ends with the latency of its longest walks (hundreds of dependent node fetches on a deep BLAS): the
+        // fewer, larger launches a frame is cut into, the less of it is spent draining (C2, 256 spp: 617 / 629 / 637
+        // Msamples/s at 32 / 64 / 128 samples per pass).
+        uint64_t target = 128ull << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t per_path = 4ull * PBRS_STATE_WORDS + 3ull * 4 + 2ull * 64;  // columns + queues + shadow records
+            // what this context already holds for paths counts as available: the answer must not change between calls
+            const uint64_t fit = ((uint64_t)free_b + (uint64_t)c->cap_slots * per_path) / 4 / per_path;
+            if (fit < target) target = fit < (4ull << 20) ? (4ull << 20) : fit;
+        }
         k = P >= target ? 1 : target / P;
     }
     if (k > spp) k = spp;
@@ -345,7 +354,7 @@ int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params*
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t P = p->w * p->h;
     const uint32_t spp = p->strata_x * p->strata_y;
-    const uint32_t K = auto_samples_per_pass(p);
+    const uint32_t K = auto_samples_per_pass(c, p);
     rcode = ensure_work(c, (size_t)P * K, P);
     if (rcode) return rcode;
     RenderConst rc = make_const(cam, p);
@@ -630,7 +639,7 @@ int pbrs_render_tile(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_para
     if (!rgb_out_host) return fail(c, PBRS_E_INVALID, "null output");
     int rc = check_params(c, cam, p);
     if (rc) return rc;
-    rc = ensure_work(c, (size_t)p->w * p->h * auto_samples_per_pass(p), (size_t)p->w * p->h);
+    rc = ensure_work(c, (size_t)p->w * p->h * auto_samples_per_pass(c, p), (size_t)p->w * p->h);
     if (rc) return rc;
     rc = render_common(c, cam, p, c->rgb_dev);
     if (rc) return rc;

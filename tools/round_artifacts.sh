@@ -19,8 +19,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$c.log 2>&1 || { tail -5 $out/pmc_$c.log; exit 1; }
   python3 $R/tools/pmc_summary.py $out/pmc_$c > $out/pmc_$(echo $c | tr A-Z a-z).txt
 done
-# default C2 bench: 1024x1024 pixels, 32 samples per pass
-python3 $R/tools/traffic_from_pmc.py $out/pmc_fetch_size.txt $out/pmc_write_size.txt $((1024*1024*32)) $((1024*1024)) > $out/traffic.json || exit 1
+# default C2 bench: 1024x1024 pixels, 128 samples per pass
+python3 $R/tools/traffic_from_pmc.py $out/pmc_fetch_size.txt $out/pmc_write_size.txt $((1024*1024*128)) $((1024*1024)) > $out/traffic.json || exit 1
 rm -rf $out/trace $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 cd $R && timeout -k 10 600 python3 bench.py > $out/bench.log 2>&1; grep '^{"metric"' $out/bench.log > $out/bench.json
 ls -la $out
