@@ -11,6 +11,8 @@ import os
 
 import numpy as np
 
+from .spec import SceneSpec
+
 from . import spec as _spec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -75,7 +77,8 @@ GPU_SYMBOLS = ["pbrs_create", "pbrs_destroy", "pbrs_last_error", "pbrs_set_strea
                "pbrs_render_tile_device", "pbrs_collect_stats", "pbrs_intersect_rays", "pbrs_camera_rays", "pbrs_numeric_eval",
                "pbrs_render_sample_radiance"]
 HOST_SYMBOLS = ["pbrs_host_scene_build", "pbrs_host_scene_free", "pbrs_host_scene_desc", "pbrs_host_scene_camera",
-                "pbrs_host_scene_stack_depth", "pbrs_host_last_error"]
+                "pbrs_host_scene_stack_depth", "pbrs_host_last_error",
+                "pbrs_host_load_pbrt", "pbrs_loaded_scene_spec", "pbrs_loaded_scene_free", "pbrs_host_load_error"]
 
 _host = None
 _gpu = None
@@ -101,6 +104,11 @@ def host_lib():
         L.pbrs_host_scene_stack_depth.restype = C.c_uint32
         L.pbrs_host_scene_stack_depth.argtypes = [C.c_void_p]
         L.pbrs_host_last_error.restype = C.c_char_p
+        L.pbrs_host_load_pbrt.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.pbrs_loaded_scene_spec.restype = C.POINTER(SceneSpec)
+        L.pbrs_loaded_scene_spec.argtypes = [C.c_void_p]
+        L.pbrs_loaded_scene_free.argtypes = [C.c_void_p]
+        L.pbrs_host_load_error.restype = C.c_char_p
         _host = L
     return _host
 
@@ -132,6 +140,34 @@ def gpu_lib():
 
 
 INTEGRATORS = {"path": 0, "direct": 1}  # PBRS_INTEGRATOR_*
+
+
+class LoadedScene:
+    """A scene read from a pbrt-v3 file by the host library (include/pbrs_host.h, pbrs_host_load_pbrt).  Stands where a
+    SceneBuilder stands: `build()` returns the scene spec, so HostScene(...) and the oracle take it as they take a builder."""
+
+    def __init__(self, path):
+        h = C.c_void_p()
+        rc = host_lib().pbrs_host_load_pbrt(os.fsencode(path), C.byref(h))
+        if rc != 0:
+            raise PbrsError(f"pbrs_host_load_pbrt({path}) failed ({rc}): {host_lib().pbrs_host_load_error().decode()}")
+        self._h = h
+        self.spec = host_lib().pbrs_loaded_scene_spec(h).contents
+
+    def build(self):
+        return self.spec
+
+    def close(self):
+        if getattr(self, "_h", None):
+            host_lib().pbrs_loaded_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def load_pbrt(path):
+    return LoadedScene(path)
 
 
 class HostScene:

@@ -1,0 +1,214 @@
+"""pbrt-v3 front-end (pbrs_amd/csrc/host/pbrt_loader.cpp; scene_parser/src/*, scene/src/loader.rs, plyloader.rs, PNG image
+maps).  The reference has no tests or scene files for this layer ("parity unpinned"), so the loader is checked against
+scenes assembled directly through the spec: same arrays, same images from the oracle."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import pbrs_amd
+from oracle.binding import OracleScene
+from pbrs_amd import spec
+from pbrs_amd.spec import SceneBuilder, Transform, deg
+
+f32 = np.float32
+
+
+def write_png(path, rgb8):
+    """8-bit RGB, filter type chosen per row so that every PNG filter is exercised."""
+    h, w, ch = rgb8.shape
+    raw = bytearray()
+    prev = np.zeros((w * ch,), dtype=np.int32)
+    for y in range(h):
+        cur = rgb8[y].reshape(-1).astype(np.int32)
+        ft = y % 5
+        a = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        c = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            pred = 0
+        elif ft == 1:
+            pred = a
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (a + prev) // 2
+        else:
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        raw.append(ft)
+        raw.extend(((cur - pred) & 255).astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    ctype = {1: 0, 3: 2, 4: 6}[ch]
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+
+
+def write_ply(path, positions, faces, normals=None, big_endian=False):
+    e = ">" if big_endian else "<"
+    props = ["x", "y", "z"] + (["nx", "ny", "nz"] if normals is not None else [])
+    header = ["ply", "format binary_%s_endian 1.0" % ("big" if big_endian else "little"), "comment made by the test",
+              "element vertex %d" % len(positions)] + ["property float %s" % p for p in props] + [
+              "element face %d" % len(faces), "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as f:
+        f.write(("\n".join(header) + "\n").encode())
+        for i, p in enumerate(positions):
+            vals = list(p) + (list(normals[i]) if normals is not None else [])
+            f.write(struct.pack(e + "%df" % len(vals), *vals))
+        for face in faces:
+            f.write(struct.pack(e + "B%di" % len(face), len(face), *face))
+
+
+PBRT = """
+# a small scene exercising the supported directives
+LookAt 0 2.5 -7   0 1 0   0 1 0
+Camera "perspective" "float fov" [ 55 ]
+Sampler "halton" "integer pixelsamples" 16
+Film "image" "integer xresolution" [ 64 ] "integer yresolution" [ 48 ] "string filename" "out.exr"
+Filter "gaussian" "float xwidth" 2.0
+WorldBegin
+  Texture "grid" "color" "imagemap" "string filename" "tex.png"
+  MakeNamedMaterial "shiny" "string type" "plastic" "rgb Kd" [ .2 .3 .7 ] "rgb Ks" [ .5 .5 .5 ] "float roughness" 0.1
+  LightSource "distant" "point from" [ 0 0 0 ] "point to" [ .3 -1 .4 ] "rgb L" [ 1.5 1.5 1.2 ]
+  LightSource "point" "point from" [ 1 4 -2 ] "color L" [ 30 30 25 ]
+  AttributeBegin
+    Material "matte" "texture Kd" "grid"
+    Shape "trianglemesh" "integer indices" [ 0 1 2 2 1 3 ] "point P" [ -8 0 -8  8 0 -8  -8 0 8  8 0 8 ]
+          "float uv" [ 0 0 1 0 0 1 1 1 ] "normal N" [ 0 1 0 0 1 0 0 1 0 0 1 0 ]
+  AttributeEnd
+  AttributeBegin
+    NamedMaterial "shiny"
+    Translate -2.2 1 0
+    Scale 1 1 1
+    Shape "sphere" "float radius" 1
+  AttributeEnd
+  AttributeBegin
+    Material "glass" "float eta" 1.4
+    TransformBegin
+      Translate 0.3 1 .5
+      Shape "sphere"
+    TransformEnd
+    Material "mirror"
+    Translate 2.6 0 0
+    Rotate 30 0 1 0
+    Shape "plymesh" "string filename" "box.ply"
+  AttributeEnd
+  AttributeBegin
+    AreaLightSource "diffuse" "rgb L" [ 8 8 8 ]
+    Translate 0 5 0
+    Shape "sphere" "float radius" .7
+  AttributeEnd
+  AttributeBegin
+    Material "uber" "rgb Kd" [ .3 .2 .1 ] "rgb Ks" [ .4 .4 .4 ] "rgb Kr" [ .5 .5 .5 ] "float roughness" .2 "float eta" 1.3
+    Include "more.pbrt"
+  AttributeEnd
+WorldEnd
+"""
+MORE = 'Translate -0.8 0.6 2.5  Shape "sphere" "float radius" 0.6\n'
+
+BOX_POS = [(-0.7, 0, -0.7), (0.7, 0, -0.7), (0.7, 0, 0.7), (-0.7, 0, 0.7), (-0.7, 1.6, -0.7), (0.7, 1.6, -0.7), (0.7, 1.6, 0.7), (-0.7, 1.6, 0.7)]
+BOX_FACES = [(0, 1, 2, 3), (7, 6, 5, 4), (0, 4, 5, 1), (1, 5, 6, 2), (2, 6, 7, 3), (3, 7, 4, 0)]  # quads: fans of two triangles
+
+
+@pytest.fixture()
+def scene_dir(tmp_path):
+    rs = np.random.RandomState(0)
+    img = (rs.rand(7, 9, 3) * 255).astype(np.uint8)
+    write_png(tmp_path / "tex.png", img)
+    write_ply(tmp_path / "box.ply", BOX_POS, BOX_FACES)
+    (tmp_path / "scene.pbrt").write_text(PBRT)
+    (tmp_path / "more.pbrt").write_text(MORE)
+    return tmp_path, img
+
+
+def _expected(img):
+    """The same scene through the builder, following scene/src/loader.rs."""
+    sb = SceneBuilder()
+    tex = sb.image(img.astype(f32) / f32(255.0))
+    shiny = sb.plastic((.2, .3, .7), (.5, .5, .5), 0.1, True)
+    sb.distant_light((.3, -1, .4), (1.5, 1.5, 1.2), float("inf"))
+    sb.point_light((1, 4, -2), (30, 30, 25))
+    floor = sb.lambertian(tex)
+    sb.instance(sb.mesh([(-8, 0, -8), (8, 0, -8), (-8, 0, 8), (8, 0, 8)], [(0, 1, 0)] * 4, [(0, 0), (1, 0), (0, 1), (1, 1)], [(0, 1, 2), (2, 1, 3)]), floor)
+    sb.instance(sb.sphere((0, 0, 0), 1.0), shiny, Transform.translater((-2.2, 1, 0)))
+    glass = sb.dielectric(1.4)
+    sb.instance(sb.sphere((0, 0, 0), 1.0), glass, Transform.translater((0.3, 1, .5)))
+    mirror = sb.mirror((0.9, 0.9, 0.9))
+    tris = []
+    for q in BOX_FACES:
+        tris += [(q[0], q[1], q[2]), (q[0], q[2], q[3])]
+    pos = np.array(BOX_POS, dtype=f32)
+    fn = np.zeros_like(pos)
+    for (i, j, k) in tris:  # geometry::compute_normals
+        n = np.cross(pos[j] - pos[i], pos[k] - pos[i]).astype(f32)
+        for v in (i, j, k):
+            fn[v] = (fn[v] + n).astype(f32)
+    fn = (fn * (f32(1.0) / np.sqrt((fn * fn).sum(axis=1, dtype=f32)))[:, None]).astype(f32)
+    # ctm = Translate(2.6,0,0) * Rotate(-30 deg about y): `ctm * parse_transform(t)`, angle negated (loader.rs:786-797)
+    box_xf = Transform.translater((2.6, 0, 0)) @ Transform.rotater([0, 1, 0], -deg(30.0))
+    sb.instance(sb.mesh(pos, fn, np.zeros((8, 2)), tris), mirror, box_xf)
+    e = (8.0, 8.0, 8.0)
+    lm = sb.diffuse_light(e)
+    sb.instance(sb.sphere((0, 0, 0), 0.7), lm, Transform.translater((0, 5, 0)))
+    sb.area_light(e, sb.sphere((0, 5, 0), 0.7))
+    uber = sb.uber((.3, .2, .1), (.4, .4, .4), kr=(.5, .5, .5), rough=(0.2, 0.2), eta=1.3, opacity=1.0)
+    sb.instance(sb.sphere((0, 0, 0), 0.6), uber, Transform.translater((-0.8, 0.6, 2.5)))
+    sb.set_camera(64, 48, deg(55.0), (0, 2.5, -7), (0, 1, 0))
+    return sb
+
+
+def test_loaded_scene_equals_the_builder_scene(scene_dir):
+    d, img = scene_dir
+    ls = pbrs_amd.load_pbrt(str(d / "scene.pbrt"))
+    s = ls.build()
+    assert (s.n_instances, s.n_meshes, s.n_area_lights, s.n_delta_lights, s.n_textures) == (6, 2, 1, 2, 1)
+    assert (s.camera.width, s.camera.height) == (64, 48)
+    tex = np.ctypeslib.as_array(s.textures[0].data, shape=(7, 9, 3))
+    assert (tex == img.astype(f32) / f32(255.0)).all(), "PNG decoding (all five row filters) and Color::rgb"
+    a, sa = OracleScene(ls).render(2, 2, 5, 3)
+    b, sb_ = OracleScene(_expected(img)).render(2, 2, 5, 3)
+    assert sa["closest_rays"] == sb_["closest_rays"] and sa["shadow_rays"] == sb_["shadow_rays"]
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    assert a.std() > 0.05
+    # and the host flattener takes it like any other scene
+    hs = pbrs_amd.HostScene(ls)
+    assert hs.desc.n_instances == 6 and hs.desc.n_textures == 1
+
+
+def test_area_light_from_a_ply_mesh_becomes_isolated_triangles(tmp_path):
+    write_ply(tmp_path / "quad.ply", [(-1, 3, -1), (1, 3, -1), (1, 3, 1), (-1, 3, 1)], [(0, 1, 2, 3)], normals=[(0, -1, 0)] * 4, big_endian=True)
+    (tmp_path / "s.pbrt").write_text("""
+LookAt 0 1 -5 0 1 0 0 1 0  Camera "perspective"  Film "image" "integer xresolution" [32] "integer yresolution" [24]
+WorldBegin
+AttributeBegin AreaLightSource "diffuse" "rgb L" [5 4 3] Scale 2 2 2 Shape "plymesh" "string filename" "quad.ply" AttributeEnd
+AttributeBegin Material "matte" Shape "sphere" AttributeEnd
+LightSource "infinite" "rgb L" [.1 .2 .3]
+WorldEnd
+""")
+    ls = pbrs_amd.load_pbrt(str(tmp_path / "s.pbrt"))  # owns the arrays the spec points at
+    s = ls.build()
+    assert s.n_area_lights == 2 and s.n_instances == 3 and s.camera.fov_y_rad == float(deg(60.0))
+    assert [s.area_lights[i].shape.kind for i in range(2)] == [spec.SHAPE_TRIANGLE] * 2
+    assert list(s.area_lights[0].shape.p) == [-2, 6, -2, 2, 6, -2, 2, 6, 2]          # world space (Scale 2)
+    assert list(s.shapes[s.instances[0].shape].p) == [-1, 3, -1, 1, 3, -1, 1, 3, 1]  # object space + the instance transform
+    assert list(s.env_constant) == [f32(.1), f32(.2), f32(.3)] and s.env_kind == spec.ENV_CONSTANT
+
+
+@pytest.mark.parametrize("text,needle", [
+    ('WorldBegin WorldEnd', "Camera"),
+    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin ObjectBegin "a" ObjectEnd WorldEnd', "instancing"),
+    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "fourier" WorldEnd', "fourier"),
+    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Shape "sphere" WorldEnd', "material"),
+    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Bogus WorldEnd', "token"),
+    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "matte" "blackbody Kd" [6500 1] Shape "sphere" WorldEnd', "spectral"),
+])
+def test_unsupported_input_is_an_error_not_an_abort(tmp_path, text, needle):
+    (tmp_path / "bad.pbrt").write_text(text + "\n")
+    with pytest.raises(pbrs_amd.PbrsError) as e:
+        pbrs_amd.load_pbrt(str(tmp_path / "bad.pbrt"))
+    assert needle.lower() in str(e.value).lower()
