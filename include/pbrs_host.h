@@ -42,6 +42,13 @@ const pbrs_scene_spec* pbrs_loaded_scene_spec(const pbrs_loaded_scene*); /* borr
 void pbrs_loaded_scene_free(pbrs_loaded_scene*);
 const char* pbrs_host_load_error(void);
 
+/* Image output of the reference's front end (src/main.rs:28-53): `write_exr` — f32 RGB, the file a render ends in (:245) —
+ * and `write_image` — 8-bit PNG of `gamma_encode().to_u8()` pixels (radiometry/src/color.rs:13-23, :54-66).  `rgb` is
+ * row-major, 3 floats per pixel, as pbrs_render_tile returns it. */
+int pbrs_host_write_exr(const char* path, const float* rgb, uint32_t width, uint32_t height);
+int pbrs_host_write_png(const char* path, const float* rgb, uint32_t width, uint32_t height);
+const char* pbrs_host_io_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,7 +78,8 @@ GPU_SYMBOLS = ["pbrs_create", "pbrs_destroy", "pbrs_last_error", "pbrs_set_strea
                "pbrs_render_sample_radiance"]
 HOST_SYMBOLS = ["pbrs_host_scene_build", "pbrs_host_scene_free", "pbrs_host_scene_desc", "pbrs_host_scene_camera",
                 "pbrs_host_scene_stack_depth", "pbrs_host_last_error",
-                "pbrs_host_load_pbrt", "pbrs_loaded_scene_spec", "pbrs_loaded_scene_free", "pbrs_host_load_error"]
+                "pbrs_host_load_pbrt", "pbrs_loaded_scene_spec", "pbrs_loaded_scene_free", "pbrs_host_load_error",
+                "pbrs_host_write_exr", "pbrs_host_write_png", "pbrs_host_io_error"]
 
 _host = None
 _gpu = None
@@ -109,6 +110,9 @@ def host_lib():
         L.pbrs_loaded_scene_spec.argtypes = [C.c_void_p]
         L.pbrs_loaded_scene_free.argtypes = [C.c_void_p]
         L.pbrs_host_load_error.restype = C.c_char_p
+        L.pbrs_host_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.pbrs_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.pbrs_host_io_error.restype = C.c_char_p
         _host = L
     return _host
 
@@ -168,6 +172,17 @@ class LoadedScene:
 
 def load_pbrt(path):
     return LoadedScene(path)
+
+
+def write_image(path, rgb):
+    """`write_exr` (path ending in .exr: f32 RGB) or `write_image` (.png: 8-bit, sqrt-gamma) of src/main.rs:28-53 for an
+    (h, w, 3) radiance array."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w, _ = rgb.shape
+    fn = host_lib().pbrs_host_write_exr if str(path).lower().endswith(".exr") else host_lib().pbrs_host_write_png
+    rc = fn(os.fsencode(path), rgb.ctypes.data, w, h)
+    if rc != 0:
+        raise PbrsError(f"writing {path} failed ({rc}): {host_lib().pbrs_host_io_error().decode()}")
 
 
 class HostScene:
