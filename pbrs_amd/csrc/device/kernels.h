@@ -10,7 +10,8 @@
 // (slot = k * P + pixel: lanes of a wave are neighbouring pixels of one sample index, so every
 // column access is a coalesced 256-byte row per wave).  Stages communicate through u32 slot queues;
 // the `break`s of the bounce loop (pathintegrator.rs:25-27, :48-50, :67-69) become "not appended to
-// the next queue", compacted with __ballot + mbcnt prefix + one atomicAdd per wave.
+// the next queue", compacted with __ballot + mbcnt prefixes summed per block in LDS (two atomics per block).
+// Shadow rays travel as 64-byte records written at their queue position (PathState::shadow_rays).
 #pragma once
 #include "lights.h"
 #include "textures.h"
@@ -56,18 +57,6 @@ struct RenderConst {
 PD uint32_t lane_prefix(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-// Stream compaction: every lane of the wave must call this; returns the output index for lanes with pred.
-PD uint32_t wave_append(bool pred, uint32_t* counter) {
-    uint64_t mask = __ballot(pred);
-    if (mask == 0) return 0;
-    uint32_t total = (uint32_t)__popcll(mask);
-    int leader = __ffsll((unsigned long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, total);
-    base = __shfl(base, leader, 64);
-    return base + lane_prefix(mask);
-}
-
 // Column access by path slot.  Slots stay below 2^30 (check_params), so the byte offset fits 32 bits: written as
 // base + zext(slot << 2) the access compiles to the scalar-base form (global_load_dword v, v_off, s[base:base+1]) with
 // ONE shared offset register per slot instead of a 64-bit address computed per column.

@@ -3,13 +3,12 @@
 // Restates tlas/src/bvh.rs:77-113 (BvhNode::intersect / occludes), tlas/src/instance.rs:50-72 and
 // shape/src/blas.rs:422-495 (intersect_bvh / intersect_bvh_pred) for one lane = one ray.
 //
-// MI355X shape of the loop.  The reference recurses through the TLAS and runs a second, nested loop
-// per mesh instance.  On a 64-wide wave a nested loop makes every lane wait while a few lanes walk a
-// BLAS, so TLAS and BLAS share ONE pending-node stack (per lane, in LDS, lane-major) and ONE
-// "while-while" loop: the inner loop pops nodes of whichever tree the lane is in, runs the box test
-// and enters mesh instances inline (a ray transform, or nothing for an identity instance); a lane
-// leaves it only when it holds primitives to test (a BLAS leaf or an analytic shape), the wave
-// reconverges, and all lanes holding primitives run the expensive, divergent part together.
+// MI355X shape of the loop.  The reference recurses through the TLAS and runs a second, nested loop per mesh instance.
+// On a 64-wide wave nested loops make every lane wait for the slowest, so a walk is a small state machine over ONE
+// pending-node stack (per lane, in LDS, lane-major) shared by the TLAS and the BLAS of the instance being visited, and it
+// advances by single steps: a node (pop + box test), a primitive of the held leaf, or an instance boundary (ray into /
+// out of the instance's space).  The kernels (kernels.h, PBRS_STEP_WALK) run, each round, whichever steps their lanes are
+// waiting for — lanes in different phases of their walks share the instruction stream — and refill finished lanes.
 //
 // Box test.  geometry/src/bvh.rs:84-99 divides six times per node; IEEE f32 division costs ~11
 // instructions on gfx950.  `(float)((double)n * R)` with R = rn64(1/(double)d) IS the correctly rounded
