@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--samples-per-pass", type=int, default=0)
+    ap.add_argument("--integrator", default="path", choices=["path", "direct"],
+                    help="path = src/pathintegrator.rs (the BASELINE metric); direct = direct_lighting_integrator (src/directlighting.rs:14-47)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, nargs=3, default=None, metavar=("W", "H", "MSAA"), help="CPU baseline sample (default 384 384 4)")
     return ap.parse_args()
@@ -53,7 +55,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PBRS_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(config_name, depth, seed, sample):
+def cpu_baseline(config_name, depth, seed, sample, integrator="path"):
     """The oracle (C++ restatement of the reference, "port") timed on this box's host cores on a bounded
     sample of the same scene; row-parallel like the reference's rayon loop (src/main.rs:219-224)."""
     from oracle.binding import OracleScene
@@ -63,7 +65,7 @@ def cpu_baseline(config_name, depth, seed, sample):
     osc = OracleScene(sb)
     cores = host_cores()
     t = time.perf_counter()
-    _, st = osc.render(msaa, msaa, depth, seed, nthreads=cores)
+    _, st = osc.render(msaa, msaa, depth, seed, nthreads=cores, integrator=integrator)
     dt = time.perf_counter() - t
     return {
         "value": st["samples"] / dt / 1e6,
@@ -117,7 +119,7 @@ def main():
     def step(timing=False, counters=False):
         if my_rows:
             ctx.render_device(out_dev.data_ptr(), sx, sy, depth, args.seed, tile=(0, 0, W, my_rows), bands=bands,
-                              samples_per_pass=args.samples_per_pass, timing=timing, counters=counters)
+                              samples_per_pass=args.samples_per_pass, timing=timing, counters=counters, integrator=args.integrator)
         torch.cuda.synchronize()
         out_host.copy_(out_dev)
         if shared is not None:
@@ -175,7 +177,7 @@ def main():
         # last measured figure for this workload, if any, is read from profiles/ (tools/traffic_from_pmc.py).
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", f"latest_traffic_{args.config}.json")
-        full_size = (W, H, sx, sy, depth) == tuple(scenes.CONFIGS[args.config][2:7])  # launch sizes as when it was measured
+        full_size = (W, H, sx, sy, depth) == tuple(scenes.CONFIGS[args.config][2:7]) and args.integrator == "path"  # as when it was measured
         if os.path.exists(tpath) and world == 1 and full_size and not args.samples_per_pass:
             with open(tpath) as f:
                 measured = json.load(f)["kernels"]
@@ -201,7 +203,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{int(args.config[1]) - 1}] ({args.config}): {W}x{H}, {spp} spp ({sx}x{sy} strata), "
                                    f"path depth {depth}, frame tiled over {world} GPU(s) in interleaved {tiling.BAND_ROWS}-row bands",
-                       "scene": args.config, "width": W, "height": H, "spp": spp, "depth": depth, "seed": args.seed},
+                       "scene": args.config, "width": W, "height": H, "spp": spp, "depth": depth, "seed": args.seed,
+                       "integrator": args.integrator},
             "mrays_per_s": rays_per_step * args.steps / elapsed / 1e6,
             "rays_per_step": rays_per_step,
             "frame_mean_radiance": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)],
@@ -220,7 +223,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             sample = tuple(args.cpu_sample) if args.cpu_sample else (384, 384, 4)
-            result["cpu_baseline"] = cpu_baseline(args.config, depth, args.seed, sample)
+            result["cpu_baseline"] = cpu_baseline(args.config, depth, args.seed, sample, args.integrator)
         print(json.dumps(result))
     if shared is not None:
         shared.close()
