@@ -131,7 +131,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the first frame allocates the path state (tens of GB): it is never a timed one, whatever --warmup says
+    for _ in range(max(args.warmup, 1)):
         step()
     barrier()
     t0 = time.perf_counter()
