@@ -602,9 +602,13 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
             t_nee += s_cnt[w][1];
             t_sh += s_cnt[w][2] + s_cnt[w][3];
         }
-        s_base[0] = t_alive ? atomicAdd(count_out, t_alive) : 0u;
+        uint32_t a = 0u;
         unsigned long long packed = 0ull;
-        if (t_nee | t_sh) packed = atomicAdd(nee_shadow_count, ((unsigned long long)t_sh << 32) | (unsigned long long)t_nee);
+        if (t_alive | t_nee | t_sh) {  // both in flight before either is waited for: the whole block sits out their latency
+            a = atomicAdd(count_out, t_alive);
+            packed = atomicAdd(nee_shadow_count, ((unsigned long long)t_sh << 32) | (unsigned long long)t_nee);
+        }
+        s_base[0] = a;
         s_base[1] = (uint32_t)packed;
         s_base[2] = (uint32_t)(packed >> 32);
     }
