@@ -54,9 +54,6 @@ struct RenderConst {
     uint64_t seed;
 };
 
-PD uint32_t lane_prefix(uint64_t mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 // Column access by path slot.  Slots stay below 2^30 (check_params), so the byte offset fits 32 bits: written as
 // base + zext(slot << 2) the access compiles to the scalar-base form (global_load_dword v, v_off, s[base:base+1]) with
 // ONE shared offset register per slot instead of a 64-bit address computed per column.
@@ -126,6 +123,9 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #ifndef PBRS_TRAV_WAVES  // min waves per SIMD asked of the register allocator for k_extend / k_shadow
 #define PBRS_TRAV_WAVES 5
 #endif
+#ifndef PBRS_LEAN_EXTEND_WAVES  // ... and for the k_extend variants without the per-candidate shading check: 80 VGPRs, two
+#define PBRS_LEAN_EXTEND_WAVES 6  // dwords of the shared leaf step spilled — C2 extend 13.6 -> 12.8 ms per 16 spp over 5 waves
+#endif
 #ifndef PBRS_SHADE_WAVES  // min waves per SIMD asked of the register allocator for k_shade (2nd arg of __launch_bounds__)
 #define PBRS_SHADE_WAVES 3
 #endif
@@ -146,7 +146,7 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #define PBRS_SHD_XFER_MIN 2
 #endif
 #ifndef PBRS_SHD_LEAF_MIN
-#define PBRS_SHD_LEAF_MIN 4
+#define PBRS_SHD_LEAF_MIN 8
 #endif
 #define PBRS_STEP_WALK(walk, S, stk, cnt, XFER_MIN, LEAF_MIN)                                                  \
     do {                                                                                                       \
@@ -161,7 +161,8 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
         if (LEAF_MIN > 1) {                                                                                    \
             const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                     \
             if (nl && (nl >= LEAF_MIN || __ballot(walk.mode == PBRS_WALK_NODE) == 0)) {                        \
-                if (walk.mode == PBRS_WALK_LEAF) walk.leaf_step(S, cnt);                                       \
+                PBRS_PROBE_LEAF_COUNT(cnt);                                                                    \
+                walk.leaf_wave(S, cnt);                                                                        \
             }                                                                                                  \
         } else if (walk.mode == PBRS_WALK_LEAF) {                                                              \
             walk.leaf_step(S, cnt);                                                                            \
@@ -179,14 +180,20 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
     do {                                                                                          \
         if (STATS) {                                                                              \
             PBRS_PROBE_ONE(walk.mode == PBRS_WALK_NODE, cuboids);                                 \
-            PBRS_PROBE_ONE(walk.mode == PBRS_WALK_LEAF, disks);                                   \
             PBRS_PROBE_ONE(walk.mode == PBRS_WALK_XFER, spheres);                                 \
             PBRS_PROBE_ONE(true, quads);                                                          \
         }                                                                                         \
     } while (0)
+#define PBRS_PROBE_LEAF_COUNT(cnt)                               \
+    do {                                                         \
+        if (STATS) PBRS_PROBE_ONE(true, disks); /* wave-level leaf-step executions */ \
+    } while (0)
 #else
 #define PBRS_PROBE_UTIL_COUNT(walk, cnt) \
     do {                                 \
+    } while (0)
+#define PBRS_PROBE_LEAF_COUNT(cnt) \
+    do {                           \
     } while (0)
 #endif
 
@@ -253,7 +260,7 @@ PD uint32_t wave_fetch(WaveWork& w, bool need, uint32_t* heads, uint32_t n) {
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
 // handed a new ray at the next refill, the walks of the other lanes continue where they were.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_extend(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t n_direct,
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES) k_extend(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t n_direct,
                                                uint32_t* next, GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t n = queue ? *count : n_direct;
@@ -745,21 +752,35 @@ __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, 
     extern __shared__ uint32_t lds_stack[];
     LaneStack stk{lds_stack + threadIdx.x, S.world + (blockIdx.x * PBRS_TRAVERSAL_BLOCK + threadIdx.x) * 3u};
     Cnt<false> cnt;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {  // grid <= PBRS_PERSISTENT_BLOCKS
-        f3 o = ld3(origins + 3 * i), d = ld3(dirs + 3 * i);
+    // grid <= PBRS_PERSISTENT_BLOCKS; whole blocks stay in the loop together (the walks share work across a wave)
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < n;
+        f3 o = gray(0.0f), d = gray(1.0f);
+        float t_max = 0.0f;
+        if (active) {
+            o = ld3(origins + 3 * i);
+            d = ld3(dirs + 3 * i);
+            t_max = tmax[i];
+        }
         if (hits) {
             Hit h;
-            tlas_closest<false>(S, o, d, tmax[i], stk, h, cnt);
-            pbrs_hit_record r;
-            r.t = h.t;
-            r.inst = h.inst;
-            r.prim = 0;
-            if (h.inst != 0xffffffffu && S.inst[h.inst].shape_kind == PBRS_SHAPE_MESH) r.prim = S.ts[h.prim].orig;
-            r.b1 = h.b1;
-            r.b2 = h.b2;
-            hits[i] = r;
+            tlas_closest<false>(S, active, o, d, t_max, stk, h, cnt);
+            if (active) {
+                pbrs_hit_record r;
+                r.t = h.t;
+                r.inst = h.inst;
+                r.prim = 0;
+                if (h.inst != 0xffffffffu && S.inst[h.inst].shape_kind == PBRS_SHAPE_MESH) r.prim = S.ts[h.prim].orig;
+                r.b1 = h.b1;
+                r.b2 = h.b2;
+                hits[i] = r;
+            }
         }
-        if (occluded) occluded[i] = tlas_any<false>(S, o, d, tmax[i], stk, cnt) ? 1 : 0;
+        if (occluded) {
+            const bool occ = tlas_any<false>(S, active, o, d, t_max, stk, cnt);
+            if (active) occluded[i] = occ ? 1 : 0;
+        }
     }
 }
 

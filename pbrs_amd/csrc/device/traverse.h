@@ -124,6 +124,53 @@ PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, 
 #define PBRS_WALK_DONE 3u
 #define PBRS_WALK_XFER 4u  // at an instance boundary: about to enter one (TLAS leaf popped) or to leave one (its entries are used up)
 
+// Triangle tests are the longest step of a walk (a division, three cross products, three more divisions) and at any one
+// time only some lanes of a wave hold a leaf, with one to four triangles each.  Run per lane, a wave-level execution of
+// the step tests one triangle for each of those lanes and leaves the rest of the wave idle, and a lane needs as many
+// executions as its leaf has triangles.  Instead the wave shares the tests out: every (owner lane, k-th triangle of its
+// leaf) pair, k < 4, gets a helper lane, the helper fetches the owner's ray through ds_bpermute, runs the test, and the
+// owner folds its pairs' results in leaf order — the values and their order are those of the sequential loop
+// (blas.rs:440-452).  Pair (owner, k) sits at helper lane (number of pairs with smaller k) + (owners with a k-th triangle
+// in lower lanes): wave-uniform ballots and mbcnt.  Lane 63 is never a helper (it takes the ds_permute writes of lanes
+// with nothing to send); pairs that would land on 63 or beyond wait for the next execution.
+PD uint32_t lane_prefix(uint64_t mask) {  // set bits of a wave mask below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+struct TriShare {
+    uint32_t tag;     // as a helper: 0x10000 | k << 8 | owner lane — whose triangle this lane tests; 0 = none
+    uint32_t cnt;     // as an owner: triangles of this lane's leaf tested in this execution
+    uint64_t has[4];  // wave-uniform: lanes that want a k-th triangle tested
+    uint32_t off[4];  // wave-uniform: pairs with smaller k
+
+    PD void build(uint32_t want) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t o = 0;
+        tag = 0;
+        cnt = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint64_t m = __ballot(want > j);
+            has[j] = m;
+            off[j] = o;
+            if (m == 0) continue;
+            const uint32_t p = o + lane_prefix(m);
+            const bool send = want > j && p < 63u;
+            tag |= (uint32_t)__builtin_amdgcn_ds_permute((int)((send ? p : 63u) << 2), send ? (int)(lane | j << 8 | 0x10000u) : 0);
+            cnt += send ? 1u : 0u;
+            o += (uint32_t)__popcll(m);
+        }
+    }
+    PD bool helper() const { return tag != 0u; }
+    PD uint32_t k() const { return (tag >> 8) & 3u; }
+    PD uint32_t pos(uint32_t j) const { return off[j] + lane_prefix(has[j]); }  // helper lane of this lane's j-th triangle, j < cnt
+    PD uint32_t from_owner(uint32_t v) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tag << 2), (int)v); }
+    PD float from_owner(float v) const { return __uint_as_float(from_owner(__float_as_uint(v))); }
+    PD f3 from_owner(f3 v) const { return mk3(from_owner(v.x), from_owner(v.y), from_owner(v.z)); }
+    PD float from_helper(uint32_t at, float v) const {
+        return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(at << 2), (int)__float_as_uint(v)));
+    }
+};
+
 template <bool STATS, uint32_t FEAT>
 struct ClosestWalk {
     RaySpace C;  // the space the lane is walking in (the world ray in the TLAS, the instance's ray below a TLAS leaf): one
@@ -286,6 +333,10 @@ struct ClosestWalk {
             if (mode == PBRS_WALK_NODE) lt = mt;
             return;
         }
+        analytic_leaf(S, cnt);
+    }
+    PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
+        const uint32_t kind = inst_info & 7u;
         mode = PBRS_WALK_NODE;
         if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
         // an analytic shape in its own space (C), extent = the TLAS extent at entry (lt)
@@ -324,6 +375,72 @@ struct ClosestWalk {
             mprim = 0;
             mb1 = b1;
             mb2 = b2;
+        }
+    }
+
+    // The held leaves of the whole wave in one execution (TriShare); every lane of the wave calls this together.
+    PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
+        const uint32_t kind = inst_info & 7u;
+        const bool tri_leaf =
+            mode == PBRS_WALK_LEAF && (!(FEAT & PBRS_FEAT_ANALYTIC) || kind == PBRS_SHAPE_MESH || kind == PBRS_SHAPE_TRIANGLE);
+        if ((FEAT & PBRS_FEAT_ANALYTIC) && mode == PBRS_WALK_LEAF && !tri_leaf) analytic_leaf(S, cnt);
+        TriShare sh;
+        sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
+        if (sh.has[0] == 0) return;
+        // helper: the owner's ray in the owner's space, the extent from before its leaf (blas.rs:440-452)
+        const f3 ho = sh.from_owner(C.o), hd = sh.from_owner(C.d);
+        const float hlt = sh.from_owner(lt);
+        const uint32_t hti = sh.from_owner(leaf_a) + sh.k();
+        const uint32_t hinfo = (STATS || (FEAT & PBRS_FEAT_SHADING_CHECK)) ? sh.from_owner(inst_info) : 0u;
+        const float hmt = (FEAT & PBRS_FEAT_SHADING_CHECK) ? sh.from_owner(mt) : 0.0f;
+        float rt = pn_inf(), rb1 = 0.0f, rb2 = 0.0f;
+        if (sh.helper()) {
+            pbrs_tri_verts tv = load_tri(S.tv + hti);
+            CNT(triangles);
+            TriHit h;
+            bool hit = mesh_tri_hit(tv, ho, hd, hlt, h);
+            if (hit && (hinfo & 7u) == PBRS_SHAPE_MESH) CNT(tri_shading);
+            // The reference builds the shading frame of every geometric hit (blas.rs:166-206) and drops the hit when
+            // the tangent check fails (Q22).  Only a hit that would replace outer_hit can change the result (hmt is
+            // outer_hit's t before the leaf, an upper bound of it inside the leaf), and for a flat-shaded mesh the
+            // check is a host-verified property of the triangles.
+            if ((FEAT & PBRS_FEAT_SHADING_CHECK) && hit && h.t < hmt && !((hinfo >> 3) & PBRS_MESH_SHADING_OK_MASK)) {
+                f3 n, dpdu;
+                hit = mesh_tri_shading(tv, S.ts[hti], hd, h, n, dpdu);
+            }
+            if (hit) {
+                rt = h.t;
+                rb1 = h.b1;
+                rb2 = h.b2;
+            }
+        }
+        // owner: fold in leaf order, strictly smaller t replaces (blas.rs:445-450)
+        uint32_t win = 0xffffffffu, win_tri = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (sh.has[j] == 0) break;
+            const uint32_t at = sh.pos(j);
+            const float t = sh.from_helper(at, rt);
+            if (j < sh.cnt && t < mt) {
+                mt = t;
+                win = at;
+                win_tri = leaf_a + j;
+            }
+        }
+        if (__ballot(win != 0xffffffffu)) {
+            const float b1 = sh.from_helper(win, rb1), b2 = sh.from_helper(win, rb2);
+            if (win != 0xffffffffu) {
+                mprim = kind == PBRS_SHAPE_MESH ? win_tri : 0u;
+                mb1 = b1;
+                mb2 = b2;
+            }
+        }
+        if (tri_leaf) {
+            leaf_a += sh.cnt;
+            if (leaf_a == leaf_end) {
+                mode = PBRS_WALK_NODE;
+                lt = mt;  // within a leaf every triangle sees the t_max from before the leaf (blas.rs:440-452)
+            }
         }
     }
 };
@@ -426,14 +543,60 @@ struct AnyWalk {
     }
     // One primitive; an occluder ends the walk (mode DONE, occluded set).
     PD void leaf_step(const DevScene& S, Cnt<STATS>& cnt) {
-        bool hit;
         if (!(FEAT & PBRS_FEAT_ANALYTIC) || inst_kind == PBRS_SHAPE_MESH || inst_kind == PBRS_SHAPE_TRIANGLE) {
             const uint32_t ti = leaf_a++;
             pbrs_tri_verts tv = load_tri(S.tv + ti);
             CNT(triangles);
-            hit = mesh_tri_pred(tv, C.o, C.d, t_max);
+            const bool hit = mesh_tri_pred(tv, C.o, C.d, t_max);
             mode = leaf_a == leaf_end ? PBRS_WALK_NODE : PBRS_WALK_LEAF;
-        } else {
+            if (hit) {
+                occluded = true;
+                mode = PBRS_WALK_DONE;
+            }
+            return;
+        }
+        analytic_leaf(S, cnt);
+    }
+    // The held leaves of the whole wave in one execution (TriShare); every lane of the wave calls this together.
+    // `intersect_bvh_pred` stops at a leaf's first occluder (blas.rs:478-495): the owner counts its triangles up to that one.
+    PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
+        const bool tri_leaf = mode == PBRS_WALK_LEAF &&
+                              (!(FEAT & PBRS_FEAT_ANALYTIC) || inst_kind == PBRS_SHAPE_MESH || inst_kind == PBRS_SHAPE_TRIANGLE);
+        if ((FEAT & PBRS_FEAT_ANALYTIC) && mode == PBRS_WALK_LEAF && !tri_leaf) analytic_leaf(S, cnt);
+        TriShare sh;
+        sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
+        if (sh.has[0] == 0) return;
+        const f3 ho = sh.from_owner(C.o), hd = sh.from_owner(C.d);
+        const float htmax = sh.from_owner(t_max);
+        const uint32_t hti = sh.from_owner(leaf_a) + sh.k();
+        bool hit = false;
+        if (sh.helper()) {
+            pbrs_tri_verts tv = load_tri(S.tv + hti);
+            hit = mesh_tri_pred(tv, ho, hd, htmax);
+        }
+        const uint64_t hits = __ballot(hit);
+        if (tri_leaf) {
+            uint32_t tested = sh.cnt;
+            bool occ = false;
+#pragma unroll
+            for (uint32_t j = 4u; j-- > 0u;) {
+                if (j < sh.cnt && ((hits >> sh.pos(j)) & 1ull)) {
+                    tested = j + 1u;
+                    occ = true;
+                }
+            }
+            if (STATS) cnt.c.triangles += tested;
+            leaf_a += sh.cnt;
+            mode = leaf_a == leaf_end ? PBRS_WALK_NODE : PBRS_WALK_LEAF;
+            if (occ) {
+                occluded = true;
+                mode = PBRS_WALK_DONE;
+            }
+        }
+    }
+    PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
+        bool hit;
+        {
             mode = PBRS_WALK_NODE;
             if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
             const float* p = S.shapes[leaf_a].p;
@@ -466,26 +629,29 @@ struct AnyWalk {
     }
 };
 
-// One ray start to finish (parity harness; the pipeline kernels interleave walks instead).
+// One ray per lane start to finish (parity harness; the pipeline kernels interleave walks and refill lanes instead).
+// Every lane of the wave calls these together (leaf_wave); `active` = the lane has a ray.
 template <bool STATS>
-PD void tlas_closest(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
+PD void tlas_closest(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
     ClosestWalk<STATS, PBRS_FEAT_ALL> w;
     w.start(S, o, d, t_max, stk);
-    while (w.mode != PBRS_WALK_DONE) {
+    if (!active) w.mode = PBRS_WALK_DONE;
+    while (__ballot(w.mode != PBRS_WALK_DONE)) {
         if (w.mode == PBRS_WALK_XFER) w.xfer_step(S, stk, cnt);
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
-        if (w.mode == PBRS_WALK_LEAF) w.leaf_step(S, cnt);
+        if (__ballot(w.mode == PBRS_WALK_LEAF)) w.leaf_wave(S, cnt);
     }
     best = w.best;
 }
 template <bool STATS>
-PD bool tlas_any(const DevScene& S, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
+PD bool tlas_any(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneStack stk, Cnt<STATS>& cnt) {
     AnyWalk<STATS, PBRS_FEAT_ALL> w;
     w.start(S, o, d, t_max, stk);
-    while (w.mode != PBRS_WALK_DONE) {
+    if (!active) w.mode = PBRS_WALK_DONE;
+    while (__ballot(w.mode != PBRS_WALK_DONE)) {
         if (w.mode == PBRS_WALK_XFER) w.xfer_step(S, stk, cnt);
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
-        if (w.mode == PBRS_WALK_LEAF) w.leaf_step(S, cnt);
+        if (__ballot(w.mode == PBRS_WALK_LEAF)) w.leaf_wave(S, cnt);
     }
     return w.occluded;
 }

@@ -17,8 +17,10 @@ print(name, "depth", depth, "extend rays", rays, "nodes/ray %.2f (tlas %.2f blas
     nodes / rays, st["tlas_nodes"] / rays, st["blas_nodes"] / rays, st["instances"] / rays, st["triangles"] / rays))
 wn, wl, wx, it = st["cuboids"], st["disks"], st["spheres"], st["quads"]
 print("  loop rounds", it, "| rounds with node lanes", wn, "(lane utilisation %.3f)" % (nodes / (64.0 * wn) if wn else 0),
-      "| rounds with leaf lanes at entry", wl, "| rounds with boundary lanes", wx)
-print("  triangles", st["triangles"], "instances", st["instances"])
+      "| rounds with boundary lanes", wx)
+le = wl  # wave-level leaf-step executions
+print("  triangles", st["triangles"], "instances", st["instances"], "| leaf-step executions", le,
+      "(lane utilisation %.3f)" % (st["triangles"] / (64.0 * le) if le else 0))
 print("  shadow rays", st["shadow_rays"], "nodes/ray %.2f tris/ray %.2f" % (
     (st["shadow_tlas_nodes"] + st["shadow_blas_nodes"]) / max(1, st["shadow_rays"]), st["shadow_triangles"] / max(1, st["shadow_rays"])))
 print("  ms", {k: round(st[k], 3) for k in ("ms_extend", "ms_shade", "ms_shadow", "ms_total")})
