@@ -91,6 +91,47 @@ def test_every_shape_kind(gpu_ctx):
     assert (occ_ref == occ_gpu).all()
 
 
+def test_leaf_with_many_triangles(gpu_ctx):
+    """`recursive_build` stops splitting when the centroid box is thinner than 1e-8 (blas.rs:354-360), so a leaf can hold
+    any number of triangles; the kernels test four per lane and execution.  13 nested, differently tilted triangles whose
+    boxes share one midpoint make such a leaf (13 = 4 + 4 + 4 + 1), two of them coplanar (a tie: the first one wins)."""
+    from pbrs_amd.spec import SceneBuilder, deg
+    pos, idx = [], []
+    for k in range(13):
+        s, a = 0.25 * (k + 1), 0.125 * ((k * 5) % 7) - 0.25
+        if k == 9:
+            a = 0.125 * ((4 * 5) % 7) - 0.25  # same plane as triangle 4 where they overlap
+        pos += [(-s, -s, -a * s), (s, -s, -a * s), (0, s, a * s)]
+        idx.append((3 * k, 3 * k + 1, 3 * k + 2))
+    sb = SceneBuilder()
+    m = sb.lambertian((0.5, 0.5, 0.5))
+    sb.instance(sb.mesh(pos, [(0, 0, -1)] * len(pos), [(0, 0)] * len(pos), idx), m)
+    sb.point_light((0, 0, -6), (30, 30, 30))
+    sb.set_camera(96, 96, deg(60.0), (0.2, 0.1, -5), (0, 0, 0))
+    hs = pbrs_amd.HostScene(sb)
+    blas = hs.nodes("blas")
+    leaves = blas[(blas[:, 7] & 0x80000000) != 0]
+    assert (leaves[:, 7] & 0x7FFFFFFF).max() == 13
+    osc = OracleScene(sb)
+    gpu_ctx.upload(hs)
+    o, d = osc.camera_rays(0, 1, 1, 3)
+    rs = np.random.RandomState(2)
+    o = np.concatenate([o, (rs.standard_normal((20000, 3)) * 2).astype(np.float32)])
+    d = np.concatenate([d, rs.standard_normal((20000, 3)).astype(np.float32)])
+    tmax = np.where(rs.rand(len(o)) < 0.7, np.inf, rs.uniform(0.5, 6, len(o))).astype(np.float32)
+    h_ref, occ_ref, st = osc.intersect(o, d, tmax)
+    h_gpu, occ_gpu = gpu_ctx.intersect(o, d, tmax)
+    assert (h_ref["inst"] == 0).sum() > 3000 and len(np.unique(h_ref["prim"][h_ref["inst"] == 0])) == 13
+    assert_hits_equal(h_ref, h_gpu)
+    assert (occ_ref == occ_gpu).all() and occ_ref.sum() > 1000
+    img_ref, st_ref = osc.render(2, 2, 4, 5)
+    img_gpu, st_gpu = gpu_ctx.render(2, 2, 4, 5, counters=True)
+    assert (bits(img_ref) == bits(img_gpu)).all()
+    # one leaf = one order of tests for closest and any hit alike; any-hit stops at the leaf's first occluder (blas.rs:478-495)
+    assert st_gpu["triangles"] + st_gpu["shadow_triangles"] == st_ref["triangles"]
+    assert st_gpu["blas_nodes"] + st_gpu["shadow_blas_nodes"] == st_ref["blas_nodes"]
+
+
 def _leaning_scene(delta, analytic):
     """A quad in general position whose vertex normals lean into its dpdu direction by `delta`, above a floor quad."""
     from pbrs_amd.spec import SceneBuilder, Transform, deg
