@@ -130,12 +130,13 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #define PBRS_SHADE_WAVES 3
 #endif
 
-// One round of the traversal loop ("if-if"): lanes in the node state take a node step, then lanes holding a leaf test
-// one primitive, so lanes in different phases of their walks share the instruction stream.  Lanes waiting at an
-// instance boundary cross it together once PBRS_XFER_MIN of them wait, or when no lane of the wave can do anything else.
+// One round of the traversal loop ("if-if"): lanes in the node state take a node step, then the wave tests the primitives
+// of its held leaves (leaf_wave: triangle tests shared out over all 64 lanes), so lanes in different phases of their walks
+// share the instruction stream.  Lanes waiting at an instance boundary cross it together once PBRS_XFER_MIN of them wait,
+// leaves are tested once PBRS_LEAF_MIN lanes hold one — or when no lane of the wave can do anything else.
 // The thresholds differ per kernel (measured, C2 / C4): closest-hit walks gain from batching both (a triangle test with
-// its four divisions is the longest step and ran at ~14 % lane utilisation unbatched); any-hit walks have a short
-// primitive test and end at the first hit, where waiting costs more than it saves.
+// its four divisions is the longest step); any-hit walks end at the first hit, where waiting at a boundary costs more
+// than it saves.
 #ifndef PBRS_EXT_XFER_MIN
 #define PBRS_EXT_XFER_MIN 12
 #endif
@@ -153,19 +154,16 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
         const uint32_t nx = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_XFER));                         \
         if (nx) {                                                                                              \
             if (nx >= XFER_MIN || __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF) == 0) { \
+                PBRS_PROBE_XFER_COUNT(cnt);                                                                    \
                 if (walk.mode == PBRS_WALK_XFER) walk.xfer_step(S, stk, cnt);                                   \
             }                                                                                                  \
         }                                                                                                      \
         PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                                      \
         if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                                          \
-        if (LEAF_MIN > 1) {                                                                                    \
-            const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                     \
-            if (nl && (nl >= LEAF_MIN || __ballot(walk.mode == PBRS_WALK_NODE) == 0)) {                        \
-                PBRS_PROBE_LEAF_COUNT(cnt);                                                                    \
-                walk.leaf_wave(S, cnt);                                                                        \
-            }                                                                                                  \
-        } else if (walk.mode == PBRS_WALK_LEAF) {                                                              \
-            walk.leaf_step(S, cnt);                                                                            \
+        const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                         \
+        if (nl && (nl >= LEAF_MIN || __ballot(walk.mode == PBRS_WALK_NODE) == 0)) {                            \
+            PBRS_PROBE_LEAF_COUNT(cnt);                                                                        \
+            walk.leaf_wave(S, cnt);                                                                            \
         }                                                                                                      \
     } while (0)
 // developer probe (tools/util_probe.py, instrumented variant only): wave-level executions of the node and leaf steps,
@@ -180,9 +178,12 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
     do {                                                                                          \
         if (STATS) {                                                                              \
             PBRS_PROBE_ONE(walk.mode == PBRS_WALK_NODE, cuboids);                                 \
-            PBRS_PROBE_ONE(walk.mode == PBRS_WALK_XFER, spheres);                                 \
             PBRS_PROBE_ONE(true, quads);                                                          \
         }                                                                                         \
+    } while (0)
+#define PBRS_PROBE_XFER_COUNT(cnt)                               \
+    do {                                                         \
+        if (STATS) PBRS_PROBE_ONE(true, spheres); /* wave-level boundary-step executions */ \
     } while (0)
 #define PBRS_PROBE_LEAF_COUNT(cnt)                               \
     do {                                                         \
@@ -193,6 +194,9 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
     do {                                 \
     } while (0)
 #define PBRS_PROBE_LEAF_COUNT(cnt) \
+    do {                           \
+    } while (0)
+#define PBRS_PROBE_XFER_COUNT(cnt) \
     do {                           \
     } while (0)
 #endif

@@ -6,8 +6,8 @@
 // MI355X shape of the loop.  The reference recurses through the TLAS and runs a second, nested loop per mesh instance.
 // On a 64-wide wave nested loops make every lane wait for the slowest, so a walk is a small state machine over ONE
 // pending-node stack (per lane, in LDS, lane-major) shared by the TLAS and the BLAS of the instance being visited, and it
-// advances by single steps: a node (pop + box test), a primitive of the held leaf, or an instance boundary (ray into /
-// out of the instance's space).  The kernels (kernels.h, PBRS_STEP_WALK) run, each round, whichever steps their lanes are
+// advances by single steps: a node (pop + box test), the primitives of the held leaf (triangles: shared out over the
+// wave's lanes, TriShare), or an instance boundary (ray into / out of the instance's space).  The kernels (kernels.h, PBRS_STEP_WALK) run, each round, whichever steps their lanes are
 // waiting for — lanes in different phases of their walks share the instruction stream — and refill finished lanes.
 //
 // Box test.  geometry/src/bvh.rs:84-99 divides six times per node; IEEE f32 division costs ~11
@@ -304,37 +304,7 @@ struct ClosestWalk {
         }
     }
 
-    // One primitive of the held leaf: the next triangle of a BLAS leaf, or the analytic shape of a TLAS leaf.
-    PD void leaf_step(const DevScene& S, Cnt<STATS>& cnt) {
-        const uint32_t kind = inst_info & 7u;
-        if (!(FEAT & PBRS_FEAT_ANALYTIC) || kind == PBRS_SHAPE_MESH || kind == PBRS_SHAPE_TRIANGLE) {
-            const uint32_t ti = leaf_a++;
-            if (leaf_a == leaf_end) mode = PBRS_WALK_NODE;
-            pbrs_tri_verts tv = load_tri(S.tv + ti);
-            CNT(triangles);
-            TriHit h;
-            bool hit = mesh_tri_hit(tv, C.o, C.d, lt, h);
-            if (hit && kind == PBRS_SHAPE_MESH) CNT(tri_shading);
-            // The reference builds the shading frame of every geometric hit (blas.rs:166-206) and drops the
-            // hit when the tangent check fails (Q22).  Only a hit that would replace outer_hit can change the
-            // result, and for a flat-shaded mesh the check is a host-verified property of the triangles.
-            hit = hit && h.t < mt;
-            if ((FEAT & PBRS_FEAT_SHADING_CHECK) && hit && !((inst_info >> 3) & PBRS_MESH_SHADING_OK_MASK)) {
-                f3 n, dpdu;
-                hit = mesh_tri_shading(tv, S.ts[ti], C.d, h, n, dpdu);
-            }
-            if (hit) {
-                mt = h.t;
-                mprim = kind == PBRS_SHAPE_MESH ? ti : 0u;
-                mb1 = h.b1;
-                mb2 = h.b2;
-            }
-            // within a leaf every triangle sees the t_max from before the leaf (blas.rs:440-452)
-            if (mode == PBRS_WALK_NODE) lt = mt;
-            return;
-        }
-        analytic_leaf(S, cnt);
-    }
+    // The analytic shape of a TLAS leaf (per lane; triangles go through leaf_wave).
     PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
         const uint32_t kind = inst_info & 7u;
         mode = PBRS_WALK_NODE;
@@ -541,22 +511,6 @@ struct AnyWalk {
             mode = PBRS_WALK_LEAF;
         }
     }
-    // One primitive; an occluder ends the walk (mode DONE, occluded set).
-    PD void leaf_step(const DevScene& S, Cnt<STATS>& cnt) {
-        if (!(FEAT & PBRS_FEAT_ANALYTIC) || inst_kind == PBRS_SHAPE_MESH || inst_kind == PBRS_SHAPE_TRIANGLE) {
-            const uint32_t ti = leaf_a++;
-            pbrs_tri_verts tv = load_tri(S.tv + ti);
-            CNT(triangles);
-            const bool hit = mesh_tri_pred(tv, C.o, C.d, t_max);
-            mode = leaf_a == leaf_end ? PBRS_WALK_NODE : PBRS_WALK_LEAF;
-            if (hit) {
-                occluded = true;
-                mode = PBRS_WALK_DONE;
-            }
-            return;
-        }
-        analytic_leaf(S, cnt);
-    }
     // The held leaves of the whole wave in one execution (TriShare); every lane of the wave calls this together.
     // `intersect_bvh_pred` stops at a leaf's first occluder (blas.rs:478-495): the owner counts its triangles up to that one.
     PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
@@ -594,6 +548,7 @@ struct AnyWalk {
             }
         }
     }
+    // The analytic shape of a TLAS leaf (per lane); an occluder ends the walk (mode DONE, occluded set).
     PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
         bool hit;
         {

@@ -17,7 +17,7 @@ print(name, "depth", depth, "extend rays", rays, "nodes/ray %.2f (tlas %.2f blas
     nodes / rays, st["tlas_nodes"] / rays, st["blas_nodes"] / rays, st["instances"] / rays, st["triangles"] / rays))
 wn, wl, wx, it = st["cuboids"], st["disks"], st["spheres"], st["quads"]
 print("  loop rounds", it, "| rounds with node lanes", wn, "(lane utilisation %.3f)" % (nodes / (64.0 * wn) if wn else 0),
-      "| rounds with boundary lanes", wx)
+      "| boundary-step executions", wx, "(lane utilisation %.3f: one entry + one exit per instance)" % (2.0 * st["instances"] / (64.0 * wx) if wx else 0))
 le = wl  # wave-level leaf-step executions
 print("  triangles", st["triangles"], "instances", st["instances"], "| leaf-step executions", le,
       "(lane utilisation %.3f)" % (st["triangles"] / (64.0 * le) if le else 0))
