@@ -304,23 +304,24 @@ PD bool bsdf_sample_specular(const Bsdf& b, f3 wo_world, f3& f, f3& wi_out, Prob
     }
     return false;
 }
-PD f3 bsdf_eval(const Bsdf& b, f3 wo_w, f3 wi_w) {                                                          // :43-51
+// The *_l forms take wo already in the local frame (world_to_local of the same vector gives the same bits wherever it is
+// evaluated; k_shade needs hit.wo's three times per vertex).
+PD f3 bsdf_eval_l(const Bsdf& b, f3 wo, f3 wi_w) {                                                          // :43-51
     f3 wi = world_to_local(b, wi_w);
-    f3 wo = world_to_local(b, wo_w);
     if (wo.z == 0.0f) return gray(0.0f);
     f3 sum = gray(0.0f);
     for (uint32_t i = 0; i < b.n; ++i) sum = sum + bxdf_eval(b.lobe(i), b.albedo_at(i), wo, wi);
     return sum;
 }
-PD float bsdf_pdf(const Bsdf& b, f3 wo_w, f3 wi_w) {  // :53-57 (Q7)
+PD f3 bsdf_eval(const Bsdf& b, f3 wo_w, f3 wi_w) { return bsdf_eval_l(b, world_to_local(b, wo_w), wi_w); }
+PD float bsdf_pdf_l(const Bsdf& b, f3 wo, f3 wi_w) {  // :53-57 (Q7)
     f3 wi = world_to_local(b, wi_w);
-    f3 wo = world_to_local(b, wo_w);
     float sum = 0.0f;
     for (uint32_t i = 0; i < b.n; ++i) sum += dens_of(bxdf_prob(b.lobe(i), wo, wi));
     return sum;
 }
-PD void bsdf_sample(const Bsdf& b, f3 wo_world, float u, float v, f3& f, f3& wi_out, ProbD& pr) {  // :59-103
-    f3 wo = world_to_local(b, wo_world);
+PD float bsdf_pdf(const Bsdf& b, f3 wo_w, f3 wi_w) { return bsdf_pdf_l(b, world_to_local(b, wo_w), wi_w); }
+PD void bsdf_sample_l(const Bsdf& b, f3 wo, float u, float v, f3& f, f3& wi_out, ProbD& pr) {  // :59-103
     if (b.n == 0) {
         f = gray(0.0f);
         wi_out = mk3(0.0f, 0.0f, 0.0f);
@@ -360,4 +361,7 @@ PD void bsdf_sample(const Bsdf& b, f3 wo_world, float u, float v, f3& f, f3& wi_
     f = bsdf_value + other_f;
     wi_out = local_to_world(b, wi);
     pr = density(overall_pdf);
+}
+PD void bsdf_sample(const Bsdf& b, f3 wo_world, float u, float v, f3& f, f3& wi_out, ProbD& pr) {
+    bsdf_sample_l(b, world_to_local(b, wo_world), u, v, f, wi_out, pr);
 }

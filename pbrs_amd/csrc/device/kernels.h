@@ -437,6 +437,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                 float lu = pn_rng_f32(&rng), lv = pn_rng_f32(&rng);
                 float su = pn_rng_f32(&rng), sv = pn_rng_f32(&rng);
                 float scale = 1.0f / light_pdf;
+                const f3 wo_l = world_to_local(bs, is.wo);  // once for eval, pdf and the MIS sample below
                 f3 c1 = gray(0.0f), c2 = gray(0.0f);
                 ShadowRay v1, v2;
                 v1.t_max = -1.0f;
@@ -448,7 +449,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     f3 li, wi;
                     ShadowRay vis;
                     delta_sample_incident(S.dlights[chosen], is, li, wi, vis);
-                    f3 bv = bsdf_eval(bs, is.wo, wi) * pn_abs(dot(is.normal, wi));
+                    f3 bv = bsdf_eval_l(bs, wo_l, wi) * pn_abs(dot(is.normal, wi));
                     if (!(is_black(li) || is_black(bv))) {
                         c1 = cmul(bv, li) * 1.0f * pn_weak_recip(1.0f);
                         v1 = vis;
@@ -462,8 +463,8 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     area_sample_incident(Lt, is, lu, lv, li, wi, lpdf, vis);
                     PBRS_SHADE_MARK(2);  // NEE: draws + light sample + its pdf
                     if (lpdf > 0.0f && !is_black(li)) {
-                        f3 bv = bsdf_eval(bs, is.wo, wi) * pn_abs(dot(is.normal, wi));
-                        float spdf = bsdf_pdf(bs, is.wo, wi);
+                        f3 bv = bsdf_eval_l(bs, wo_l, wi) * pn_abs(dot(is.normal, wi));
+                        float spdf = bsdf_pdf_l(bs, wo_l, wi);
                         if (!is_black(bv) && spdf > 0.0f) {
                             float weight = power_heuristic2(lpdf, spdf);
                             c1 = cmul(bv, li) * weight * pn_weak_recip(lpdf);
@@ -473,7 +474,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     PBRS_SHADE_MARK(3);  // NEE term 1: BSDF eval + pdf + MIS weight
                     f3 f2, wi2;
                     ProbD pr2;
-                    bsdf_sample(bs, is.wo, su, sv, f2, wi2, pr2);
+                    bsdf_sample_l(bs, wo_l, su, sv, f2, wi2, pr2);
                     f2 = f2 * pn_abs(dot(is.normal, wi2));
                     if (!(is_black(f2) || !(pr2.v > 0.0f))) {
                         f3 le;
@@ -491,7 +492,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     mode = 2;
                     f3 f2, wi2;
                     ProbD pr2;
-                    bsdf_sample(bs, is.wo, su, sv, f2, wi2, pr2);
+                    bsdf_sample_l(bs, wo_l, su, sv, f2, wi2, pr2);
                     spawn_ray(is, wi2, v1.o, v1.d);
                     v1.t_max = pn_inf();
                     float ac = pn_abs(dot(wi2, is.normal));
