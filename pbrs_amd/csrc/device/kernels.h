@@ -699,6 +699,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
                     walk.start(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, stk);
                     nrays++;
                 }
+                walk.scan_wave(S, cnt);
                 live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
             if (live == 0) break;

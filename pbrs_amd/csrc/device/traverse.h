@@ -122,6 +122,7 @@ PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, 
 #define PBRS_WALK_NODE 1u
 #define PBRS_WALK_LEAF 2u
 #define PBRS_WALK_DONE 3u
+#define PBRS_WALK_SCAN 5u  // just started on a small TLAS: waits, within the refill, for the wave's shared scan of the leaf boxes
 #define PBRS_WALK_XFER 4u  // at an instance boundary: about to enter one (TLAS leaf popped) or to leave one (its entries are used up)
 
 // Triangle tests are the longest step of a walk (a division, three cross products, three more divisions) and at any one
@@ -168,6 +169,65 @@ struct TriShare {
     PD f3 from_owner(f3 v) const { return mk3(from_owner(v.x), from_owner(v.y), from_owner(v.z)); }
     PD float from_helper(uint32_t at, float v) const {
         return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(at << 2), (int)__float_as_uint(v)));
+    }
+};
+
+// Shared scan of a small TLAS (DevScene::tlas_flat).  Lanes that have just been given a ray ("fresh") need every leaf box
+// of the scene tested against it; run per lane that is one node step per leaf with the other lanes of the wave looking on.
+// Instead each fresh lane gets H = ceil(n_flat / 2) helper slots, a slot tests leaves h and h + H against the owner's ray
+// (pulled through ds_bpermute once per slot), and the owner collects its ray's pass bits from two ballots.  The box test
+// does not depend on anything the walk changes except t_max, and only closest-hit walks change that (ClosestWalk::shrunk).
+struct FlatScan {
+    PD static uint32_t pull(uint32_t from, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
+    PD static float pull(uint32_t from, float v) { return __uint_as_float(pull(from, __float_as_uint(v))); }
+    PD static double pull(uint32_t from, double v) {
+        return __hiloint2double((int)pull(from, (uint32_t)__double2hiint(v)), (int)pull(from, (uint32_t)__double2loint(v)));
+    }
+    // Returns, to each fresh lane, the mask of the leaves whose box its ray R (on the division-free test) passes within
+    // t_max; `tested` counts the box tests this lane ran as a helper.  Every lane of the wave calls this together;
+    // S.n_flat <= PBRS_FLAT_TLAS_MAX = 16.
+    PD static uint32_t run(const DevScene& S, bool fresh, const RaySpace& R, float t_max, uint32_t& tested) {
+        const uint64_t m = __ballot(fresh);
+        if (m == 0) return 0u;
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t H = (S.n_flat + 1u) >> 1;  // 4..8 slots per owner
+        const uint32_t total = (uint32_t)__popcll(m) * H;
+        const uint32_t rank = lane_prefix(m);
+        // lane r learns which lane holds the r-th fresh ray (the others write to lane 63, which no rank reaches unless all 64 are fresh)
+        const uint32_t list = (uint32_t)__builtin_amdgcn_ds_permute((int)((fresh ? rank : 63u) << 2), (int)lane);
+        const uint32_t magic = (65536u + H - 1u) / H;  // p / H == p * magic >> 16 for p < 1024
+        uint32_t mine = 0;
+        for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t p = base + lane;
+            const bool valid = p < total;
+            const uint32_t r = (p * magic) >> 16, h = p - r * H;
+            const uint32_t owner = pull(r, list);
+            RaySpace O;
+            O.o = mk3(pull(owner, R.o.x), pull(owner, R.o.y), pull(owner, R.o.z));
+            O.d = gray(0.0f);  // not read by the division-free test
+            O.rx = pull(owner, R.rx);
+            O.ry = pull(owner, R.ry);
+            O.rz = pull(owner, R.rz);
+            O.fast = true;
+            const float ot = pull(owner, t_max);
+            bool pass0 = false, pass1 = false;
+            if (valid) {
+                pass0 = slab_rs(load_node(S.tlas_flat + h), O, ot);
+                tested += 1u;
+                if (h + H < S.n_flat) {
+                    pass1 = slab_rs(load_node(S.tlas_flat + h + H), O, ot);
+                    tested += 1u;
+                }
+            }
+            const uint64_t w0 = __ballot(pass0), w1 = __ballot(pass1);
+            const int sft = (int)(rank * H) - (int)base;  // this lane's first slot, relative to the window
+            if (fresh && sft > -(int)H && sft < 64) {
+                const uint64_t a = sft >= 0 ? w0 >> sft : w0 << -sft, b = sft >= 0 ? w1 >> sft : w1 << -sft;
+                const uint32_t keep = (1u << H) - 1u;
+                mine |= ((uint32_t)a & keep) | (((uint32_t)b & keep) << H);
+            }
+        }
+        return mine;
     }
 };
 
@@ -426,7 +486,7 @@ struct AnyWalk {
     float t_max;
     uint32_t leaf_a, leaf_end, inst_kind;
     int sp, blas_base;
-    uint32_t tl;
+    uint32_t cand;  // leaves of DevScene::tlas_flat still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, occluded, moved;
     uint32_t mode;
 
@@ -438,35 +498,48 @@ struct AnyWalk {
         occluded = false;
         blas_base = 0;
         leaf_a = leaf_end = inst_kind = 0;
+        cand = 0;
         if ((FEAT & PBRS_FEAT_FLAT_TLAS) && S.n_flat != 0u && C.fast) {
-            tl = 0;
             sp = 0;
+            mode = PBRS_WALK_SCAN;
         } else {
-            tl = (FEAT & PBRS_FEAT_FLAT_TLAS) ? S.n_flat : 0u;
             stk.put(0, 0u);
             sp = 1;
+            mode = PBRS_WALK_NODE;
         }
-        mode = PBRS_WALK_NODE;
+    }
+    // The leaf boxes of a small TLAS against the rays that have just started (FlatScan); every lane of the wave calls this
+    // together, right after start().  Any-hit: nothing a box test depends on changes during the walk.
+    PD void scan_wave(const DevScene& S, Cnt<STATS>& cnt) {
+        if (!(FEAT & PBRS_FEAT_FLAT_TLAS)) return;
+        uint32_t tested = 0;
+        const uint32_t mine = FlatScan::run(S, mode == PBRS_WALK_SCAN, C, t_max, tested);
+        if (STATS) cnt.c.tlas_nodes += tested;
+        if (mode == PBRS_WALK_SCAN) {
+            cand = mine;
+            mode = PBRS_WALK_NODE;
+        }
     }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
         if (in_blas && sp == blas_base) {
             mode = PBRS_WALK_XFER;
             return;
         }
-        uint32_t ni;
-        const pbrs_node* nodes;
-        if (sp == 0) {
-            if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || tl >= S.n_flat) {
+        if (sp == 0) {  // not inside an instance (its exit was taken above), nothing pending: the next scanned leaf, or the end
+            if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || cand == 0u) {
                 mode = PBRS_WALK_DONE;
                 return;
             }
-            ni = tl++;
-            nodes = S.tlas_flat;
-        } else {
-            ni = stk.get(--sp);
-            nodes = in_blas ? S.blas : S.tlas;
+            const uint32_t k = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1u;
+            const pbrs_node leaf = load_node(S.tlas_flat + k);  // its box passed in scan_wave
+            leaf_a = leaf.a;
+            inst_kind = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+            mode = PBRS_WALK_XFER;
+            return;
         }
-        const pbrs_node node = load_node(nodes + ni);
+        const uint32_t ni = stk.get(--sp);
+        const pbrs_node node = load_node((in_blas ? S.blas : S.tlas) + ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
@@ -603,6 +676,7 @@ PD bool tlas_any(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneSt
     AnyWalk<STATS, PBRS_FEAT_ALL> w;
     w.start(S, o, d, t_max, stk);
     if (!active) w.mode = PBRS_WALK_DONE;
+    w.scan_wave(S, cnt);
     while (__ballot(w.mode != PBRS_WALK_DONE)) {
         if (w.mode == PBRS_WALK_XFER) w.xfer_step(S, stk, cnt);
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
