@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
                     walk.start(S, o, d, pn_inf(), stk);
                     nrays++;
                 }
+                walk.scan_wave(S, cnt);
                 live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
             if (live == 0) break;

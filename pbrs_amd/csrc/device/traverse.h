@@ -241,7 +241,7 @@ struct ClosestWalk {
     uint32_t inst_info;  // of the instance the lane is in: shape kind | mesh flags << 3 | bit 31: an analytic candidate is held
     uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or leaf_a = the analytic shape
     int sp, blas_base;
-    uint32_t tl;          // next leaf of DevScene::tlas_flat (== n_flat when the lane walks the TLAS tree instead)
+    uint32_t cand;        // leaves of DevScene::tlas_flat still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, moved;  // moved: C differs from the parked world ray
     uint32_t mode;
 
@@ -259,15 +259,30 @@ struct ClosestWalk {
         mprim = cur_inst = inst_info = leaf_a = leaf_end = 0;
         mb1 = mb2 = 0.0f;
         blas_base = 0;
+        cand = 0;
         if ((FEAT & PBRS_FEAT_FLAT_TLAS) && S.n_flat != 0u && C.fast) {
-            tl = 0;
             sp = 0;
+            mode = PBRS_WALK_SCAN;
         } else {
-            tl = (FEAT & PBRS_FEAT_FLAT_TLAS) ? S.n_flat : 0u;
             stk.put(0, 0u);
             sp = 1;
+            mode = PBRS_WALK_NODE;
         }
-        mode = PBRS_WALK_NODE;
+    }
+    // The leaf boxes of a small TLAS against the rays that have just started (FlatScan); every lane of the wave calls this
+    // together, right after start().  For a closest-hit walk the scan is a filter: the reference tests a leaf's box when
+    // its recursion gets there, with the t_max of that moment, and so does node_step for the leaves that are left.  The
+    // filter runs with an infinite extent — a box the ray misses at any distance — because t_max does not only come down:
+    // a mesh may return a hit beyond the extent it was given (blas.rs:468) and `set_extent` then raises it (bvh.rs:84-88).
+    PD void scan_wave(const DevScene& S, Cnt<STATS>& cnt) {
+        if (!(FEAT & PBRS_FEAT_FLAT_TLAS)) return;
+        uint32_t tested = 0;
+        const uint32_t mine = FlatScan::run(S, mode == PBRS_WALK_SCAN, C, pn_inf(), tested);
+        if (STATS) cnt.c.tlas_nodes += tested;
+        if (mode == PBRS_WALK_SCAN) {
+            cand = mine;
+            mode = PBRS_WALK_NODE;
+        }
     }
 
     // One node: pop, box test, then push the children / hold the leaf / stop at the instance boundary.
@@ -276,20 +291,22 @@ struct ClosestWalk {
             mode = PBRS_WALK_XFER;
             return;
         }
-        uint32_t ni;
-        const pbrs_node* nodes;
-        if (sp == 0) {  // not inside an instance (its exit was taken above)
-            if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || tl >= S.n_flat) {
+        if (sp == 0) {  // not inside an instance (its exit was taken above), nothing pending: the next scanned leaf, or the end
+            if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || cand == 0u) {
                 mode = PBRS_WALK_DONE;
                 return;
             }
-            ni = tl++;
-            nodes = S.tlas_flat;
-        } else {
-            ni = stk.get(--sp);
-            nodes = in_blas ? S.blas : S.tlas;
+            const uint32_t k = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1u;
+            const pbrs_node leaf = load_node(S.tlas_flat + k);
+            if (!slab_rs(leaf, C, t_max)) return;  // the test the reference makes, at its time (scan_wave only filters)
+            cur_inst = leaf.a;
+            inst_info = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+            mode = PBRS_WALK_XFER;
+            return;
         }
-        const pbrs_node node = load_node(nodes + ni);
+        const uint32_t ni = stk.get(--sp);
+        const pbrs_node node = load_node((in_blas ? S.blas : S.tlas) + ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
@@ -664,6 +681,7 @@ PD void tlas_closest(const DevScene& S, bool active, f3 o, f3 d, float t_max, La
     ClosestWalk<STATS, PBRS_FEAT_ALL> w;
     w.start(S, o, d, t_max, stk);
     if (!active) w.mode = PBRS_WALK_DONE;
+    w.scan_wave(S, cnt);
     while (__ballot(w.mode != PBRS_WALK_DONE)) {
         if (w.mode == PBRS_WALK_XFER) w.xfer_step(S, stk, cnt);
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
