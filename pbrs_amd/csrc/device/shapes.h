@@ -28,12 +28,13 @@ struct DevScene {
     float env[3];
     uint32_t has_env;
     uint32_t fast_slab;  // node coordinates are inside the range the f64-reciprocal box test is exact for (traverse.h)
-    // Small TLAS (<= PBRS_FLAT_TLAS_MAX instances): its leaves alone, in pre-order = the order the tree walk reaches them.
+    // Small TLAS (PBRS_FLAT_TLAS_MIN..MAX instances): its leaves alone, in pre-order = the order the tree walk reaches them.
     // A box inside a box that a ray misses is missed too (each slab bound is a correctly rounded, hence monotonic,
-    // function of the box coordinate), so testing every leaf in this order processes exactly the leaves, in exactly the
-    // order, of the reference's recursion (tlas/src/bvh.rs:84-88) without visiting the inner nodes.  Only for rays on
-    // the division-free box test (no NaN quotients); other rays walk the tree.  Built for PBRS_FLAT_TLAS_MIN..MAX
-    // instances (n_flat = 0 otherwise; kernels without PBRS_FEAT_FLAT_TLAS do not contain the scan).
+    // function of the box coordinate), so testing the leaf boxes in this order — each against the t_max of its turn —
+    // processes exactly the leaves, in exactly the order, of the reference's recursion (tlas/src/bvh.rs:84-88) without
+    // visiting the inner nodes.  The wave runs those tests for its new rays together (traverse.h, FlatScan).  Only for
+    // rays on the division-free box test (no NaN quotients); other rays walk the tree.  n_flat = 0 outside the range
+    // (kernels without PBRS_FEAT_FLAT_TLAS do not contain the scan).
     const pbrs_node* tlas_flat;
     uint32_t n_flat;
     uint32_t features;   // PBRS_FEAT_*: what the traversal kernels must be able to do for this scene
@@ -53,7 +54,7 @@ struct DevScene {
 #define PBRS_FEAT_SHADING_CHECK 2u  // some mesh needs the tangent check of blas.rs:193-200 evaluated per candidate hit
 #define PBRS_FEAT_FLAT_TLAS 4u      // DevScene::tlas_flat is built: rays on the division-free box test scan the TLAS leaves
 #define PBRS_FEAT_ALL 7u
-#define PBRS_FLAT_TLAS_MIN 8u   // below this the tree walk visits about as many nodes as there are leaves
+#define PBRS_FLAT_TLAS_MIN 2u
 #define PBRS_FLAT_TLAS_MAX 16u
 
 // Per-lane work counters (instrumented kernel variant only; SURVEY.md §8(d) units).

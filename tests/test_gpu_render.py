@@ -33,12 +33,13 @@ def test_image_matches_golden_and_counters(gpu_ctx, name):
     assert st["closest_rays"] == want["closest_rays"] and st["shadow_rays"] == want["shadow_rays"]
     assert st["shade_events"] == want["shade_events"] and st["samples"] == want["samples"]
     hs = pbrs_amd.HostScene(sb)
-    if not 8 <= hs.desc.n_instances <= 16:
+    if not 2 <= hs.desc.n_instances <= 16:
         assert st["tlas_nodes"] + st["shadow_tlas_nodes"] == want["tlas_nodes"]
     else:
-        # a TLAS of 8..16 instances is scanned leaf by leaf in pre-order (same leaves, same order, no inner-node visits:
-        # DevScene::tlas_flat) by every ray that is on the division-free box test; the others walk the tree
-        assert st["tlas_nodes"] + st["shadow_tlas_nodes"] <= want["tlas_nodes"]
+        # a TLAS of 2..16 instances is not walked: the wave tests every leaf box for each new ray (FlatScan, rays on the
+        # division-free box test) and the walk visits the leaves that passed, in pre-order; the box-test count is then
+        # leaves x rays, not the reference's.  The instances entered — what the boxes decide — are compared below.
+        assert st["tlas_nodes"] + st["shadow_tlas_nodes"] <= hs.desc.n_instances * (st["closest_rays"] + st["shadow_rays"]) + want["tlas_nodes"]
     assert st["instances"] + st["shadow_instances"] == want["instances"]
     # any-hit visits BLAS children near-first (order-free for a boolean), so only its ray and TLAS counts are
     # comparable with the reference's left-first recursion; closest-hit counts are comparable in full
