@@ -118,6 +118,9 @@ PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, 
 // bit-identical t from two instances (oracle counter tlas_ties).
 // Walk states.  A kernel advances every lane by single steps — one node (pop + box test) or one primitive — so that
 // lanes of one wave that are in different phases of their walks still share the instruction stream (k_extend).
+#ifndef PBRS_EARLY_OUT  // a failed box test that leaves nothing pending below the instance goes to the boundary state at once
+#define PBRS_EARLY_OUT 1
+#endif
 #define PBRS_WALK_IDLE 0u
 #define PBRS_WALK_NODE 1u
 #define PBRS_WALK_LEAF 2u
@@ -311,7 +314,10 @@ struct ClosestWalk {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
         }
-        if (!slab_rs(node, C, in_blas ? lt : t_max)) return;
+        if (!slab_rs(node, C, in_blas ? lt : t_max)) {
+            if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = PBRS_WALK_XFER;
+            return;
+        }
         if (!(node.b & PBRS_LEAF_FLAG)) {
             // TLAS: left (i+1) is popped first.  BLAS: the child the ray enters first along the split axis
             // (blas.rs:456-466), and the cloned ray's t_max follows outer_hit (blas.rs:468).
@@ -384,7 +390,7 @@ struct ClosestWalk {
     // The analytic shape of a TLAS leaf (per lane; triangles go through leaf_wave).
     PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
         const uint32_t kind = inst_info & 7u;
-        mode = PBRS_WALK_NODE;
+        mode = PBRS_WALK_XFER;  // the shape was all there is below this TLAS leaf: straight to the way out
         if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
         // an analytic shape in its own space (C), extent = the TLAS extent at entry (lt)
         const float* p = S.shapes[leaf_a].p;
@@ -485,7 +491,7 @@ struct ClosestWalk {
         if (tri_leaf) {
             leaf_a += sh.cnt;
             if (leaf_a == leaf_end) {
-                mode = PBRS_WALK_NODE;
+                mode = sp == blas_base ? PBRS_WALK_XFER : PBRS_WALK_NODE;  // nothing pending below this instance: what node_step would find
                 lt = mt;  // within a leaf every triangle sees the t_max from before the leaf (blas.rs:440-452)
             }
         }
@@ -561,7 +567,10 @@ struct AnyWalk {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
         }
-        if (!slab_rs(node, C, t_max)) return;
+        if (!slab_rs(node, C, t_max)) {
+            if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = PBRS_WALK_XFER;
+            return;
+        }
         if (!(node.b & PBRS_LEAF_FLAG)) {
             bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
             uint32_t left = ni + 1, right = node.a;
@@ -631,7 +640,7 @@ struct AnyWalk {
             }
             if (STATS) cnt.c.triangles += tested;
             leaf_a += sh.cnt;
-            mode = leaf_a == leaf_end ? PBRS_WALK_NODE : PBRS_WALK_LEAF;
+            mode = leaf_a != leaf_end ? PBRS_WALK_LEAF : sp == blas_base ? PBRS_WALK_XFER : PBRS_WALK_NODE;
             if (occ) {
                 occluded = true;
                 mode = PBRS_WALK_DONE;
@@ -642,7 +651,7 @@ struct AnyWalk {
     PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
         bool hit;
         {
-            mode = PBRS_WALK_NODE;
+            mode = PBRS_WALK_XFER;  // straight to the way out of the instance
             if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
             const float* p = S.shapes[leaf_a].p;
             switch (inst_kind) {
