@@ -132,6 +132,50 @@ def test_leaf_with_many_triangles(gpu_ctx):
     assert st_gpu["blas_nodes"] + st_gpu["shadow_blas_nodes"] == st_ref["blas_nodes"]
 
 
+@pytest.mark.parametrize("n_inst", [1, 2, 3, 7, 15, 16, 17, 40])
+def test_tlas_sizes_around_the_shared_scan(gpu_ctx, n_inst):
+    """TLAS of 2..16 instances: the wave tests every leaf box for its new rays (FlatScan: ceil(n / 2) helper slots per ray,
+    two leaves per slot); outside that range, and for rays off the division-free box test, the tree is walked.  Same
+    geometry recipe at every size: spheres, cuboids, quads and two-triangle meshes on a ring, some overlapping."""
+    from pbrs_amd.spec import SceneBuilder, Transform, deg
+    sb = SceneBuilder()
+    m = sb.lambertian((0.5, 0.5, 0.5))
+    for k in range(n_inst):
+        ang, r = 2.399963 * k, 1.0 + 0.35 * k ** 0.5
+        at = (r * np.cos(ang), 0.4 * np.sin(1.7 * k), r * np.sin(ang))
+        xf = Transform().rotate_y(deg(23.0 * k)).translate(at)
+        if k % 4 == 0:
+            sb.instance(sb.sphere((0, 0, 0), 0.45), m, xf)
+        elif k % 4 == 1:
+            sb.instance(sb.cuboid((-0.3, -0.4, -0.3), (0.3, 0.4, 0.3)), m, xf)
+        elif k % 4 == 2:
+            sb.instance(sb.quad((-0.5, -0.5, 0), (1, 0, 0), (0, 1, 0)), m, xf)
+        else:
+            sb.instance(sb.mesh([(-0.5, -0.5, 0), (0.5, -0.5, 0), (-0.5, 0.5, 0.2), (0.5, 0.5, 0.2)], [(0, 0, -1)] * 4,
+                                [(0, 0), (1, 0), (0, 1), (1, 1)], [(0, 1, 2), (2, 1, 3)]), m, xf)
+    sb.point_light((0, 6, 0), (40, 40, 40))
+    sb.set_camera(80, 60, deg(70.0), (0.3, 2.5, -6.5), (0, 0, 0))
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    o, d = osc.camera_rays(0, 1, 1, 9)
+    rs = np.random.RandomState(n_inst)
+    o2 = (rs.standard_normal((6000, 3)) * 2.5).astype(np.float32)
+    d2 = rs.standard_normal((6000, 3)).astype(np.float32)
+    d2[:200, 1] = 0.0  # a zero direction component: these rays walk the tree whatever the TLAS size
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    for tmax in (np.full(len(o), np.inf, dtype=np.float32), rs.uniform(0.5, 9.0, len(o)).astype(np.float32)):
+        h_ref, occ_ref, st = osc.intersect(o, d, tmax)
+        h_gpu, occ_gpu = gpu_ctx.intersect(o, d, tmax)
+        keep = ~st["tie_mask"]
+        assert (bits(h_ref["t"]) == bits(h_gpu["t"])).all()
+        assert_hits_equal(h_ref[keep], h_gpu[keep])
+        assert (occ_ref == occ_gpu).all()
+    assert (h_ref["inst"] != 0xFFFFFFFF).sum() > 20
+    img_ref, _ = osc.render(2, 2, 4, 3)
+    img_gpu, _ = gpu_ctx.render(2, 2, 4, 3)
+    assert (bits(img_ref) == bits(img_gpu)).all()
+
+
 def _leaning_scene(delta, analytic):
     """A quad in general position whose vertex normals lean into its dpdu direction by `delta`, above a floor quad."""
     from pbrs_amd.spec import SceneBuilder, Transform, deg
