@@ -13,11 +13,12 @@
 #include "dmath.h"
 
 struct DevScene {
-    const pbrs_node* tlas;
+    // Every BVH node of the scene in one array with absolute links: the TLAS at 0 (root = node 0), its leaves again at
+    // flat_off when the TLAS is small (below), then the BLASes; a mesh instance's blas_root is an index into it.
+    const pbrs_node* nodes;
     const pbrs_instance* inst;
     const pbrs_shape* shapes;
     const pbrs_mesh* meshes;
-    const pbrs_node* blas;
     const pbrs_tri_verts* tv;
     const pbrs_tri_shade* ts;
     const pbrs_material* mats;
@@ -35,8 +36,7 @@ struct DevScene {
     // visiting the inner nodes.  The wave runs those tests for its new rays together (traverse.h, FlatScan).  Only for
     // rays on the division-free box test (no NaN quotients); other rays walk the tree.  n_flat = 0 outside the range
     // (kernels without PBRS_FEAT_FLAT_TLAS do not contain the scan).
-    const pbrs_node* tlas_flat;
-    uint32_t n_flat;
+    uint32_t flat_off, n_flat;
     uint32_t features;   // PBRS_FEAT_*: what the traversal kernels must be able to do for this scene
     // texture/src/lib.rs (device/textures.h) and the environment light (scene/src/lib.rs:105-117)
     const pbrs_texture* textures;
@@ -52,7 +52,7 @@ struct DevScene {
 // instantiation: a mesh-only scene whose meshes all carry a PBRS_MESH_*_SHADING_OK flag runs the leanest one.
 #define PBRS_FEAT_ANALYTIC 1u       // some instance is an analytic shape (sphere, disk, quad, cuboid, triangle)
 #define PBRS_FEAT_SHADING_CHECK 2u  // some mesh needs the tangent check of blas.rs:193-200 evaluated per candidate hit
-#define PBRS_FEAT_FLAT_TLAS 4u      // DevScene::tlas_flat is built: rays on the division-free box test scan the TLAS leaves
+#define PBRS_FEAT_FLAT_TLAS 4u      // the leaf copies at DevScene::flat_off are built: rays on the division-free box test scan the TLAS leaves
 #define PBRS_FEAT_ALL 7u
 #define PBRS_FLAT_TLAS_MIN 2u
 #define PBRS_FLAT_TLAS_MAX 16u

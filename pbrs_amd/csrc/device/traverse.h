@@ -175,7 +175,7 @@ struct TriShare {
     }
 };
 
-// Shared scan of a small TLAS (DevScene::tlas_flat).  Lanes that have just been given a ray ("fresh") need every leaf box
+// Shared scan of a small TLAS (the leaf copies at DevScene::flat_off).  Lanes that have just been given a ray ("fresh") need every leaf box
 // of the scene tested against it; run per lane that is one node step per leaf with the other lanes of the wave looking on.
 // Instead each fresh lane gets H = ceil(n_flat / 2) helper slots, a slot tests leaves h and h + H against the owner's ray
 // (pulled through ds_bpermute once per slot), and the owner collects its ray's pass bits from two ballots.  The box test
@@ -215,10 +215,10 @@ struct FlatScan {
             const float ot = pull(owner, t_max);
             bool pass0 = false, pass1 = false;
             if (valid) {
-                pass0 = slab_rs(load_node(S.tlas_flat + h), O, ot);
+                pass0 = slab_rs(load_node(S.nodes + S.flat_off + h), O, ot);
                 tested += 1u;
                 if (h + H < S.n_flat) {
-                    pass1 = slab_rs(load_node(S.tlas_flat + h + H), O, ot);
+                    pass1 = slab_rs(load_node(S.nodes + S.flat_off + h + H), O, ot);
                     tested += 1u;
                 }
             }
@@ -244,7 +244,7 @@ struct ClosestWalk {
     uint32_t inst_info;  // of the instance the lane is in: shape kind | mesh flags << 3 | bit 31: an analytic candidate is held
     uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or leaf_a = the analytic shape
     int sp, blas_base;
-    uint32_t cand;        // leaves of DevScene::tlas_flat still to visit: their boxes passed the shared scan (0 on a tree walk)
+    uint32_t cand;        // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, moved;  // moved: C differs from the parked world ray
     uint32_t mode;
 
@@ -294,26 +294,24 @@ struct ClosestWalk {
             mode = PBRS_WALK_XFER;
             return;
         }
+        // One box test serves lanes at a BLAS / TLAS node and lanes whose turn it is to test a scanned leaf of a small TLAS
+        // — the test the reference makes at this moment (scan_wave only filters).
+        uint32_t ni;
         if (sp == 0) {  // not inside an instance (its exit was taken above), nothing pending: the next scanned leaf, or the end
             if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || cand == 0u) {
                 mode = PBRS_WALK_DONE;
                 return;
             }
-            const uint32_t k = (uint32_t)__builtin_ctz(cand);
+            ni = S.flat_off + (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1u;
-            const pbrs_node leaf = load_node(S.tlas_flat + k);
-            if (!slab_rs(leaf, C, t_max)) return;  // the test the reference makes, at its time (scan_wave only filters)
-            cur_inst = leaf.a;
-            inst_info = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
-            mode = PBRS_WALK_XFER;
-            return;
+        } else {
+            ni = stk.get(--sp);
+            if (STATS) {  // the scanned leaves were counted by the scan
+                if (in_blas) CNT(blas_nodes);
+                else CNT(tlas_nodes);
+            }
         }
-        const uint32_t ni = stk.get(--sp);
-        const pbrs_node node = load_node((in_blas ? S.blas : S.tlas) + ni);
-        if (STATS) {
-            if (in_blas) CNT(blas_nodes);
-            else CNT(tlas_nodes);
-        }
+        const pbrs_node node = load_node(S.nodes + ni);
         if (!slab_rs(node, C, in_blas ? lt : t_max)) {
             if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = PBRS_WALK_XFER;
             return;
@@ -509,7 +507,7 @@ struct AnyWalk {
     float t_max;
     uint32_t leaf_a, leaf_end, inst_kind;
     int sp, blas_base;
-    uint32_t cand;  // leaves of DevScene::tlas_flat still to visit: their boxes passed the shared scan (0 on a tree walk)
+    uint32_t cand;  // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, occluded, moved;
     uint32_t mode;
 
@@ -555,14 +553,14 @@ struct AnyWalk {
             }
             const uint32_t k = (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1u;
-            const pbrs_node leaf = load_node(S.tlas_flat + k);  // its box passed in scan_wave
+            const pbrs_node leaf = load_node(S.nodes + S.flat_off + k);  // its box passed in scan_wave
             leaf_a = leaf.a;
             inst_kind = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
             mode = PBRS_WALK_XFER;
             return;
         }
         const uint32_t ni = stk.get(--sp);
-        const pbrs_node node = load_node((in_blas ? S.blas : S.tlas) + ni);
+        const pbrs_node node = load_node(S.nodes + ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);

@@ -551,11 +551,29 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     free_scene(c);
     DevScene S{};
     int rc;
-    if ((rc = upload(c, d->tlas_nodes, d->n_tlas_nodes, &S.tlas))) return rc;
-    if ((rc = upload(c, d->instances, d->n_instances, &S.inst))) return rc;
+    {
+        // DevScene::nodes: the TLAS, then its leaves alone in pre-order when the TLAS is small (the shared scan), then every
+        // BLAS, in one array with absolute links — a walk reads nodes + index whatever tree it is in.
+        const bool scan = d->n_instances >= PBRS_FLAT_TLAS_MIN && d->n_instances <= PBRS_FLAT_TLAS_MAX;
+        std::vector<pbrs_node> nodes(d->tlas_nodes, d->tlas_nodes + d->n_tlas_nodes);
+        S.flat_off = (uint32_t)nodes.size();
+        if (scan)
+            for (uint32_t i = 0; i < d->n_tlas_nodes; ++i)
+                if (d->tlas_nodes[i].b & PBRS_LEAF_FLAG) nodes.push_back(d->tlas_nodes[i]);
+        S.n_flat = (uint32_t)nodes.size() - S.flat_off;
+        const uint64_t blas_off = nodes.size();
+        if (blas_off + d->n_blas_nodes > 0x7fffffffull) return fail(c, PBRS_E_LIMIT, "too many BVH nodes");
+        nodes.insert(nodes.end(), d->blas_nodes, d->blas_nodes + d->n_blas_nodes);
+        for (size_t i = blas_off; i < nodes.size(); ++i)
+            if (!(nodes[i].b & PBRS_LEAF_FLAG)) nodes[i].a += (uint32_t)blas_off;  // right child; the left one is i + 1
+        if ((rc = upload(c, nodes.data(), nodes.size(), &S.nodes))) return rc;
+        std::vector<pbrs_instance> inst(d->instances, d->instances + d->n_instances);
+        for (pbrs_instance& in : inst)
+            if (in.shape_kind == PBRS_SHAPE_MESH) in.blas_root += (uint32_t)blas_off;
+        if ((rc = upload(c, inst.data(), inst.size(), &S.inst))) return rc;
+    }
     if ((rc = upload(c, d->shapes, d->n_shapes, &S.shapes))) return rc;
     if ((rc = upload(c, d->meshes, d->n_meshes, &S.meshes))) return rc;
-    if ((rc = upload(c, d->blas_nodes, d->n_blas_nodes, &S.blas))) return rc;
     if ((rc = upload(c, d->tri_verts, d->n_triangles, &S.tv))) return rc;
     if ((rc = upload(c, d->tri_shade, d->n_triangles, &S.ts))) return rc;
     if ((rc = upload(c, d->materials, d->n_materials, &S.mats))) return rc;
@@ -588,13 +606,6 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         S.fast_slab = ok ? 1u : 0u;
     }
     S.world = c->world;
-    if (d->n_instances >= PBRS_FLAT_TLAS_MIN && d->n_instances <= PBRS_FLAT_TLAS_MAX) {  // DevScene::tlas_flat: the leaves in node-index (= pre-order) order
-        std::vector<pbrs_node> flat;
-        for (uint32_t i = 0; i < d->n_tlas_nodes; ++i)
-            if (d->tlas_nodes[i].b & PBRS_LEAF_FLAG) flat.push_back(d->tlas_nodes[i]);
-        if ((rc = upload(c, flat.data(), (uint32_t)flat.size(), &S.tlas_flat))) return rc;
-        S.n_flat = (uint32_t)flat.size();
-    }
     const uint32_t flat_feature = S.n_flat ? PBRS_FEAT_FLAT_TLAS : 0u;
     S.features = flat_feature;
     for (uint32_t i = 0; i < d->n_instances; ++i) {
