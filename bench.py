@@ -182,8 +182,9 @@ def main():
         if os.path.exists(tpath) and world == 1 and full_size and not args.samples_per_pass:
             with open(tpath) as f:
                 measured = json.load(f)["kernels"]
-            # the uninstrumented instantiation(s) of the dominant kernel, e.g. "k_extend<false, 0u>"
-            tk = [v for k, v in measured.items() if k == dom["kernel"] or k.startswith(dom["kernel"] + "<false")]
+            # the uninstrumented instantiation(s) of the dominant kernel, e.g. "k_extend<false, 4u>", "k_shade<0u, false>"
+            tk = [v for k, v in measured.items()
+                  if k == dom["kernel"] or (k.startswith(dom["kernel"] + "<") and not k.startswith(dom["kernel"] + "<true"))]
             if tk:
                 traffic = sum(v["hbm_total"] * v["launches"] for v in tk) / sum(v["launches"] for v in tk)
                 traffic_src = os.path.relpath(tpath, ROOT)
