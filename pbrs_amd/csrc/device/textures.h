@@ -42,6 +42,12 @@ PD float perlin_turbulance(const DevScene& S, const pbrs_texture& t, f3 p) {  //
 // `(x) as usize` of Rust: saturating, NaN -> 0
 PD uint64_t to_usize(float x) { return x != x ? 0ull : (x <= 0.0f ? 0ull : (x >= 1.8446744e19f ? ~0ull : (uint64_t)x)); }
 
+PD f3 tex_image_value(const DevScene& S, const pbrs_texture& t, float u, float v) {  // Image :211-223
+    const float uc = pn_clamp(u, 0.0f, 1.0f), vc = pn_clamp(v, 0.0f, 1.0f);
+    const uint64_t col = to_usize(uc * (float)t.width) % t.width;
+    const uint64_t row = to_usize(vc * (float)t.height) % t.height;
+    return ld3(S.tex_floats + t.data + 3ull * (row * t.width + col));
+}
 PD f3 tex_value(const DevScene& S, uint32_t id, float u, float v, f3 p) {
     const pbrs_texture& t = S.textures[id];
     if (t.kind == PBRS_TEX_CHECKER) {  // :40-49
@@ -50,11 +56,7 @@ PD f3 tex_value(const DevScene& S, uint32_t id, float u, float v, f3 p) {
     }
     if (t.kind == PBRS_TEX_PERLIN)  // :150-160, a marble-like texture
         return pn_mul_add(pn_sin(t.freq * p.z + 10.0f * perlin_turbulance(S, t, p)), 0.5f, 0.5f) * gray(1.0f);
-    // Image :211-223
-    const float uc = pn_clamp(u, 0.0f, 1.0f), vc = pn_clamp(v, 0.0f, 1.0f);
-    const uint64_t col = to_usize(uc * (float)t.width) % t.width;
-    const uint64_t row = to_usize(vc * (float)t.height) % t.height;
-    return ld3(S.tex_floats + t.data + 3ull * (row * t.width + col));
+    return tex_image_value(S, t, u, v);
 }
 
 // Scene::eval_env_light (scene/src/lib.rs:105-117)
@@ -65,7 +67,8 @@ PD f3 env_eval(const DevScene& S, f3 dir) {
             const float u = pn_fract(phi * PN_FRAC_1_PI * 0.5f + 1.0f);
             const float cos_theta = dir.y / norm(dir);
             const float v = pn_acos(cos_theta) / PN_PI;
-            return cmul(tex_value(S, S.env_texture, u, v, mk3(0.0f, 0.0f, 0.0f)), ld3(S.env_scale));
+            // pbrs_upload_scene only accepts an Image texture here: the kernels of untextured scenes stay free of the other kinds
+            return cmul(tex_image_value(S, S.textures[S.env_texture], u, v), ld3(S.env_scale));
         }
         case PBRS_ENV_BLUE_SKY: {  // preset.rs:25-30
             const float y = (hat(dir).y + 1.0f) * 0.5f;
