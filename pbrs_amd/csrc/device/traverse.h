@@ -26,21 +26,22 @@ struct RaySpace {
     double rx, ry, rz;  // rn64(1 / d)
     bool fast;
 };
-PD bool dir_in_range(float x) {  // normal, 2^-40 <= |x| <= 2^40
+// Branch-free (one unsigned compare per range; `&`, not `&&`): six short-circuit branches here cost more than the tests.
+PD uint32_t dir_in_range(float x) {  // normal, 2^-40 <= |x| <= 2^40
     uint32_t e = (pn_bits(x) >> 23) & 0xffu;
-    return e >= 127u - 40u && e <= 127u + 40u;
+    return (e - (127u - 40u) <= 80u) ? 1u : 0u;
 }
-PD bool origin_in_range(float x) {  // zero, or 2^-60 <= |x| <= 2^40
+PD uint32_t origin_in_range(float x) {  // zero, or 2^-60 <= |x| <= 2^40
     uint32_t u = pn_bits(x) & 0x7fffffffu;
     uint32_t e = u >> 23;
-    return u == 0u || (e >= 127u - 60u && e <= 127u + 40u);
+    return ((u == 0u) | (e - (127u - 60u) <= 100u)) ? 1u : 0u;
 }
 PD RaySpace make_space(f3 o, f3 d, bool scene_ok) {
     RaySpace r;
     r.o = o;
     r.d = d;
-    r.fast = scene_ok && dir_in_range(d.x) && dir_in_range(d.y) && dir_in_range(d.z) && origin_in_range(o.x) && origin_in_range(o.y) &&
-             origin_in_range(o.z);
+    r.fast = ((scene_ok ? 1u : 0u) & dir_in_range(d.x) & dir_in_range(d.y) & dir_in_range(d.z) & origin_in_range(o.x) &
+              origin_in_range(o.y) & origin_in_range(o.z)) != 0u;
     r.rx = r.ry = r.rz = 0.0;
     if (r.fast) {
         r.rx = 1.0 / (double)d.x;
