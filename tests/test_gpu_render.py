@@ -65,6 +65,32 @@ def test_image_matches_oracle(gpu_ctx, cfg, w, h, sx, sy, depth, kw):
     assert (bits(img) == bits(ref)).all()
 
 
+@pytest.mark.parametrize("cfg,w,h,sx,sy,kw", [("c4", 80, 45, 4, 2, {"nx": 96, "nz": 160}), ("c3", 64, 64, 2, 2, {})])
+def test_shading_check_kernels_give_the_same_image(gpu_ctx, cfg, w, h, sx, sy, kw):
+    """The host proves, per mesh, that the tangent check of blas.rs:193-200 cannot fail (PBRS_MESH_*_SHADING_OK) and the
+    traversal kernels then skip the shading frame of every candidate.  With the proofs cleared the same scene runs through
+    the kernel variants that evaluate it for each candidate (helper lanes of the shared triangle step, four-triangle leaves
+    on C4's mesh): same image, same counters, and both equal the oracle's."""
+    import ctypes as C
+    sb, _ = scenes.build_config(cfg, width=w, height=h, **kw)
+    hs = pbrs_amd.HostScene(sb)
+    gpu_ctx.upload(hs)
+    img, st = gpu_ctx.render(sx, sy, 8, 7, counters=True)
+    d = hs.desc
+    meshes = np.ctypeslib.as_array(C.cast(d.meshes, C.POINTER(C.c_uint32)), shape=(d.n_meshes, 8))       # pbrs_mesh.flags: word 5
+    insts = np.ctypeslib.as_array(C.cast(d.instances, C.POINTER(C.c_uint32)), shape=(d.n_instances, 32))  # pbrs_instance.mesh_flags: word 29
+    assert (meshes[:, 5] & 3).any()
+    meshes[:, 5] &= ~np.uint32(3)
+    insts[:, 29] &= ~np.uint32(3)
+    gpu_ctx.upload(hs)
+    img2, st2 = gpu_ctx.render(sx, sy, 8, 7, counters=True)
+    assert (bits(img) == bits(img2)).all()
+    for k in ("closest_rays", "shadow_rays", "tlas_nodes", "blas_nodes", "triangles", "tri_shading", "instances", "instance_hits"):
+        assert st[k] == st2[k], k
+    ref, _ = OracleScene(sb).render(sx, sy, 8, 7)
+    assert (bits(img2) == bits(ref)).all()
+
+
 def test_materials_and_lights_outside_the_baseline_scenes(gpu_ctx):
     """Uber (5 lobes, swap_remove order), Substrate, Glossy, anisotropic Beckmann, point + distant lights (Q6 guard),
     disk + quad area lights, constant environment."""
