@@ -143,7 +143,8 @@ typedef struct pbrs_material {
     uint32_t n_bxdfs;
     uint32_t first_bxdf;
     uint32_t flags; /* PBRS_MATERIAL_TEXTURED: some lobe has tex != 0 */
-    uint32_t pad[2];
+    uint32_t vis_class; /* palette entry of material_visualizer for `Material::summary()`, src/directlighting.rs:247-259 */
+    uint32_t pad;
 } pbrs_material;
 #define PBRS_MATERIAL_TEXTURED 1u
 
@@ -273,6 +274,10 @@ typedef struct pbrs_render_params {
  * specular reflection/refraction (src/bsdf.rs:104-113) followed by direct_lighting_debug_integrator (:49-56).  max_depth
  * only gates it (`depth <= 0` returns black); the chain is at most two rays long. */
 #define PBRS_INTEGRATOR_DIRECT 1u
+/* material_visualizer, src/directlighting.rs:234-271 (`--visualize-materials`, src/main.rs:166-187): one un-jittered ray per
+ * pixel (`shoot_ray(row, col, (0.0, 0.0))`), a palette colour per kind of material at the first hit, a grey checker of
+ * the ray direction where nothing is hit.  strata must be 1 x 1; max_depth is ignored (the reference passes 0). */
+#define PBRS_INTEGRATOR_MATERIALS 2u
 
 /* Renders a tile; replaces src/main.rs:192-231 for the rows/cols of the tile.  `rgb_out` is
  * w*h*3 floats, row-major.  _host writes to caller-owned host memory (one D2H copy at the end);

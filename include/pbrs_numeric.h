@@ -93,6 +93,13 @@ PN_FN float pn_floor(float x) {
 }
 /* f32::fract = self - self.trunc() */
 PN_FN float pn_fract(float x) { return x - pn_trunc(x); }
+/* `x as i32` of Rust: toward zero, saturating, NaN -> 0 */
+PN_FN int32_t pn_f32_to_i32(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (int32_t)(-2147483647 - 1);
+    return (int32_t)x;
+}
 
 /* compiler-rt __powisf2 / LLVM's constant-exponent expansion: square-and-multiply, LSB first. */
 PN_FN float pn_powi(float a, int b) {

@@ -330,6 +330,33 @@ static Color direct_lighting_debug_integrator(const Scene& scene, Ray ray, uint6
     }
     return scene.eval_env_light(ray);
 }
+// material_visualizer (src/directlighting.rs:234-271): a palette colour for the kind of material at the first hit
+// (`match mtl.summary()`, summaries in material/src/lib.rs), a grey checker of the ray direction where nothing is hit.
+static Color material_visualizer(const Scene& scene, Ray ray) {
+    static const uint8_t pal8[7][3] = {{232, 207, 59}, {124, 188, 126}, {30, 68, 176}, {15, 142, 205}, {44, 180, 172}, {216, 39, 252}, {143, 112, 252}};
+    Hit h;
+    REF_COUNT(closest_rays);
+    if (scene.tlas->intersect(ray, &h)) {
+        REF_COUNT(shade_events);
+        int index;
+        switch (h.inst->mtl->spec.kind) {  // the first arm whose string the summary contains
+            case PBRS_MTL_LAMBERTIAN: index = 8; break;     // "Lambertian"
+            case PBRS_MTL_METAL: index = 7; break;          // "Metal{ior = ...}"
+            case PBRS_MTL_MIRROR: index = 5; break;         // "Mirror{albedo = ...}"
+            case PBRS_MTL_DIELECTRIC: index = 4; break;     // "Dielectric{ior = ...}"
+            case PBRS_MTL_DIFFUSE_LIGHT: index = 3; break;  // "DiffuseLight{emit = ...}"
+            case PBRS_MTL_UBER: index = 2; break;           // "uber"
+            case PBRS_MTL_SUBSTRATE: index = 1; break;      // "substrate"
+            case PBRS_MTL_PLASTIC: index = 0; break;        // "plastic"
+            default: index = 9; break;                      // "Glossy" matches no arm
+        }
+        if (index < 7) return Color{(float)pal8[index][0] / 255.0f, (float)pal8[index][1] / 255.0f, (float)pal8[index][2] / 255.0f};  // Color::rgb
+        return index == 7 ? gray(0.3f) : index == 8 ? gray(0.9f) : black();
+    }
+    // `(x * 50.0).floor() as i32 + (y * 50.0).floor() as i32` (wrapping, as a release build adds)
+    int parity = (int)((uint32_t)pn_f32_to_i32(pn_floor(ray.dir.x * 50.0f)) + (uint32_t)pn_f32_to_i32(pn_floor(ray.dir.y * 50.0f)));
+    return parity % 2 == 0 ? gray(0.9f) : gray(0.7f);
+}
 // direct_lighting_integrator (:14-47): emitters return their emission; everything else the one-light estimate plus one
 // level of perfect-specular reflection/refraction followed by the debug integrator.
 static Color direct_lighting_integrator(const Scene& scene, Ray ray, int depth, uint64_t* rng) {
@@ -398,12 +425,13 @@ int oracle_render_tile(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_
     return oracle_render_tile_integrator(os, x0, y0, w, h, strata_x, strata_y, max_depth, seed, nthreads, 0, rgb_out, stats_out);
 }
 
-// `integrator`: 0 = path_integrator (src/pathintegrator.rs), 1 = direct_lighting_integrator (src/directlighting.rs:14-47);
-// both fit the reference's seam `fn(&Scene, Ray, i32) -> Color` (src/main.rs:160-163).
+// `integrator`: 0 = path_integrator (src/pathintegrator.rs), 1 = direct_lighting_integrator (src/directlighting.rs:14-47),
+// 2 = material_visualizer (:234-271; strata 1 x 1, the ray goes through the pixel's corner: `shoot_ray(row, col, (0.0, 0.0))`,
+// src/main.rs:170); all fit the reference's seam `fn(&Scene, Ray, i32) -> Color` (src/main.rs:160-187).
 int oracle_render_tile_integrator(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t strata_x,
                                   uint32_t strata_y, uint32_t max_depth, uint64_t seed, uint32_t nthreads, uint32_t integrator,
                                   float* rgb_out, oracle_stats* stats_out) {
-    if (integrator > 1) return -1;
+    if (integrator > 2 || (integrator == 2 && (strata_x != 1 || strata_y != 1))) return -1;
     const Scene& scene = *os->scene;
     if (nthreads == 0) nthreads = 1;
     const uint32_t width = scene.camera.width;
@@ -426,11 +454,13 @@ int oracle_render_tile_integrator(const oracle_scene* os, uint32_t x0, uint32_t 
                     float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);
                     float jx = ((float)(i / strata_y) + r0) / (float)strata_x;
                     float jy = ((float)(i % strata_y) + r1) / (float)strata_y;
+                    if (integrator == 2) jx = jy = 0.0f;
                     Ray ray;
                     scene.camera.shoot_ray(row, col, jx, jy, &ray);
                     REF_COUNT(samples);
-                    color_sum = color_sum + (integrator == 0 ? path_integrator(scene, ray, (int)max_depth, &rng, nullptr)
-                                                             : direct_lighting_integrator(scene, ray, (int)max_depth, &rng));
+                    color_sum = color_sum + (integrator == 0   ? path_integrator(scene, ray, (int)max_depth, &rng, nullptr)
+                                             : integrator == 1 ? direct_lighting_integrator(scene, ray, (int)max_depth, &rng)
+                                                               : material_visualizer(scene, ray));
                 }
                 Color color = color_sum * (1.0f / (float)spp);  // scale_down_by, color.rs:90-95
                 float* px = rgb_out + 3 * ((size_t)ry * w + cx);

@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
     // src/main.rs:198-201 with msaa -> (strata_x, strata_y): i / msaa, i % msaa
     float jx = ((float)(i / rc.strata_y) + r0) / (float)rc.strata_x;
     float jy = ((float)(i % rc.strata_y) + r1) / (float)rc.strata_y;
+    if (rc.integrator == PBRS_INTEGRATOR_MATERIALS) jx = jy = 0.0f;  // `shoot_ray(row, col, (0.0, 0.0))`, src/main.rs:170
     // Camera::shoot_ray, camera.rs:65-77
     float x = (float)col + pn_fract(jx);
     float y = (float)row + pn_fract(jy);
@@ -368,7 +369,28 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
         // direct + (S * f) * (1 / mass): f travels in the beta columns, 1 / mass in the flags column (as float bits).
         bool emitter_hit = false;
         float post = 1.0f;
-        if (INTEG == PBRS_INTEGRATOR_PATH) {
+        if (INTEG == PBRS_INTEGRATOR_MATERIALS) {  // material_visualizer, src/directlighting.rs:234-271
+            if (has_hit) {
+                float r = 0.0f, g = 0.0f, b = 0.0f;  // pal[index], :235-246; Color::rgb = u8 / 255.0 (color.rs:51-53)
+                switch (mat->vis_class) {
+                    case 0: r = 232.0f, g = 207.0f, b = 59.0f; break;
+                    case 1: r = 124.0f, g = 188.0f, b = 126.0f; break;
+                    case 2: r = 30.0f, g = 68.0f, b = 176.0f; break;
+                    case 3: r = 15.0f, g = 142.0f, b = 205.0f; break;
+                    case 4: r = 44.0f, g = 180.0f, b = 172.0f; break;
+                    case 5: r = 216.0f, g = 39.0f, b = 252.0f; break;
+                    case 6: r = 143.0f, g = 112.0f, b = 252.0f; break;
+                    default: break;
+                }
+                L = mk3(r / 255.0f, g / 255.0f, b / 255.0f);
+                if (mat->vis_class == 7u) L = gray(0.3f);
+                if (mat->vis_class == 8u) L = gray(0.9f);
+            } else {
+                const int parity = (int)((uint32_t)pn_f32_to_i32(pn_floor(d.x * 50.0f)) + (uint32_t)pn_f32_to_i32(pn_floor(d.y * 50.0f)));
+                L = gray(parity % 2 == 0 ? 0.9f : 0.7f);
+            }
+            emitter_hit = true;  // nothing below runs for this lane
+        } else if (INTEG == PBRS_INTEGRATOR_PATH) {
             if (bounce == 0 || specular_bounce) {  // pathintegrator.rs:19-22
                 f3 e = has_hit ? ld3(mat->emission) : env_eval(S, d);
                 L = L + cmul(beta, e);

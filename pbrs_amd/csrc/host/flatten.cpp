@@ -635,6 +635,14 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
             }
         pbrs_material pm;
         flatten_material(spec->materials[m], &pm, hs->bxdfs);
+        {  // material_visualizer's `match mtl.summary()` (src/directlighting.rs:248-259; summaries: material/src/lib.rs)
+            static const uint32_t palette_of_kind[] = {/* Lambertian */ 8, /* Metal */ 7, /* Glossy: no arm */ 9, /* Mirror */ 5,
+                                                       /* plastic */ 0,    /* Dielectric */ 4, /* DiffuseLight */ 3, /* uber */ 2,
+                                                       /* substrate */ 1};
+            const uint32_t kind = spec->materials[m].kind;
+            pm.vis_class = kind <= PBRS_MTL_SUBSTRATE ? palette_of_kind[kind] : 9u;
+            pm.pad = 0;
+        }
         if (pm.n_bxdfs > PBRS_MAX_BXDFS) {
             g_error = "material with more than PBRS_MAX_BXDFS lobes";
             return PBRS_E_INVALID;

@@ -187,7 +187,9 @@ int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* 
     }
     if (p->strata_x == 0 || p->strata_y == 0) return fail(c, PBRS_E_INVALID, "zero strata");
     if (p->max_depth > kMaxDepth) return fail(c, PBRS_E_LIMIT, "max_depth above 64");
-    if (p->integrator > PBRS_INTEGRATOR_DIRECT) return fail(c, PBRS_E_INVALID, "unknown integrator");
+    if (p->integrator > PBRS_INTEGRATOR_MATERIALS) return fail(c, PBRS_E_INVALID, "unknown integrator");
+    if (p->integrator == PBRS_INTEGRATOR_MATERIALS && (p->strata_x != 1 || p->strata_y != 1))
+        return fail(c, PBRS_E_INVALID, "the material visualiser takes one un-jittered ray per pixel (strata 1 x 1)");
     if ((uint64_t)p->w * p->h > (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile above 2^28 pixels");
     // queue entries keep two flag bits next to the slot index
     if ((uint64_t)p->w * p->h * auto_samples_per_pass(c, p) >= (1ull << 30)) return fail(c, PBRS_E_LIMIT, "tile x samples_per_pass above 2^30 paths");
@@ -314,7 +316,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     tm.end();
     const size_t lds = lds_bytes(c);
     // the direct-lighting integrator is at most two rays deep whatever `depth` says (directlighting.rs:15-17, :36, :49)
-    const uint32_t n_bounces = rc.integrator == PBRS_INTEGRATOR_DIRECT ? (rc.max_depth ? 2u : 0u) : rc.max_depth;
+    const uint32_t n_bounces = rc.integrator == PBRS_INTEGRATOR_DIRECT      ? (rc.max_depth ? 2u : 0u)
+                               : rc.integrator == PBRS_INTEGRATOR_MATERIALS ? 1u  // one cast, no lights (directlighting.rs:247)
+                                                                            : rc.max_depth;
     for (uint32_t b = 0; b < n_bounces; ++b) {
         const uint32_t* qin = b == 0 ? nullptr : q[b & 1];
         if (tm.begin(1)) return fail(c, PBRS_E_DEVICE, "event record failed");
@@ -326,7 +330,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     hipLaunchKernelGGL((k_shade<I, T>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], \
                        act + b + 1, neeq, ns + b)
             const bool direct = rc.integrator == PBRS_INTEGRATOR_DIRECT;
-            if (c->textured) {  // some material evaluates a non-Solid texture per hit
+            if (rc.integrator == PBRS_INTEGRATOR_MATERIALS) {
+                PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false);
+            } else if (c->textured) {  // some material evaluates a non-Solid texture per hit
                 if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true);
                 else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true);
             } else {
@@ -380,7 +386,7 @@ int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params*
     HIPCHK(c, hipGetLastError());
     c->pending.passes = passes;
     c->pending.launches_extend = c->pending.launches_shade = c->pending.launches_shadow =
-        passes * (p->integrator == PBRS_INTEGRATOR_DIRECT ? (p->max_depth ? 2u : 0u) : p->max_depth);
+        passes * (p->integrator == PBRS_INTEGRATOR_DIRECT ? (p->max_depth ? 2u : 0u) : p->integrator == PBRS_INTEGRATOR_MATERIALS ? 1u : p->max_depth);
     return PBRS_OK;
 }
 

@@ -224,6 +224,37 @@ def _textured_scene(env):
     return sb
 
 
+def _material_zoo():
+    """One instance of every material kind in front of nothing, so that the visualiser's checker shows too."""
+    from pbrs_amd.spec import SceneBuilder, Transform, deg
+    sb = SceneBuilder()
+    mats = [sb.lambertian((0.6, 0.5, 0.4)), sb.metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.2), 0.1), sb.glossy((0.7, 0.7, 0.7), 0.2),
+            sb.mirror((0.9, 0.9, 0.9)), sb.plastic((0.3, 0.5, 0.2), (0.4, 0.4, 0.4), 0.1), sb.dielectric(1.5),
+            sb.diffuse_light((4, 4, 4)), sb.uber(kd=(0.3, 0.3, 0.5), ks=(0.2, 0.2, 0.2)), sb.substrate((0.4, 0.2, 0.2), (0.3, 0.3, 0.3))]
+    for k, m in enumerate(mats):
+        sb.instance(sb.sphere((0, 0, 0), 0.45), m, Transform.translater((-2.0 + 1.0 * (k % 5), 0.6 - 1.2 * (k // 5), 0.0)))
+    sb.point_light((0, 4, -4), (30, 30, 30))
+    sb.set_camera(120, 72, deg(50.0), (0.0, 0.0, -6.0), (0, 0, 0))
+    return sb
+
+
+@pytest.mark.parametrize("cfg", ["zoo", "c3", "c5"])
+def test_material_visualizer_matches_oracle(gpu_ctx, cfg):
+    """`--visualize-materials` (src/main.rs:166-187, src/directlighting.rs:234-271): one un-jittered ray per pixel, a
+    palette colour per kind of material, a grey checker of the ray direction where nothing is hit."""
+    sb = _material_zoo() if cfg == "zoo" else scenes.build_config(cfg, width=96, height=54)[0]
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    img, st = gpu_ctx.render(1, 1, 0, 1, integrator="materials", counters=True)
+    ref, ost = OracleScene(sb).render(1, 1, 0, 1, integrator="materials")
+    assert (bits(img) == bits(ref)).all()
+    assert st["closest_rays"] == ost["closest_rays"] == img.shape[0] * img.shape[1] and st["shadow_rays"] == 0
+    colours = {tuple(np.round(c * 255).astype(int)) for c in img.reshape(-1, 3)}
+    if cfg == "zoo":  # all nine kinds (Glossy has no arm: black; Lambertian shares its grey with the checker) and both checker greys
+        assert len(colours) == 10 and (0, 0, 0) in colours and {(230, 230, 230), (178, 178, 178)} <= colours
+    with pytest.raises(pbrs_amd.PbrsError):
+        gpu_ctx.render(2, 2, 0, 1, integrator="materials")
+
+
 @pytest.mark.parametrize("env", [None, "image", 2, 3, 4])
 @pytest.mark.parametrize("integrator", ["path", "direct"])
 def test_textures_and_environment_lights_match_oracle(gpu_ctx, env, integrator):

@@ -11,6 +11,8 @@ integrator = sys.argv[5] if len(sys.argv) > 5 else "path"
 ls = pbrs_amd.load_pbrt(scene)
 ctx = pbrs_amd.Context(0)
 ctx.upload(pbrs_amd.HostScene(ls))
+if integrator == "materials":  # --visualize-materials of the reference (src/main.rs:183-185): one ray per pixel
+    msaa = 1
 img, st = ctx.render(msaa, msaa, depth, 1, integrator=integrator, timing=True)
 pbrs_amd.write_image(out, img)
 print(f"{img.shape[1]}x{img.shape[0]} at {msaa * msaa} spp in {st['ms_total']:.1f} ms -> {out}")
