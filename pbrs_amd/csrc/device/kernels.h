@@ -115,9 +115,16 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 }
 
 // ---- extend ----------------------------------------------------------------------------------------------------
-#ifndef PBRS_REFILL_BELOW
-#define PBRS_REFILL_BELOW 40
+// A wave takes new rays when fewer than DevScene::refill_below of its lanes are walking (pbrs_upload_scene): short walks
+// (a small TLAS scanned by the wave, BLASes of a few nodes) favour late, large refills — the shared scan of the new rays
+// fills its windows and the step kernels run on fuller waves less often; long walks (C4's 18-level BLAS) favour early ones.
+#ifndef PBRS_REFILL_BELOW_SHORT
+#define PBRS_REFILL_BELOW_SHORT 20u  // C2 extend 9.23 / 8.92 / 9.04 ms per 16 spp at 40 / 24 / 16
 #endif
+#ifndef PBRS_REFILL_BELOW_LONG
+#define PBRS_REFILL_BELOW_LONG 48u   // C4 extend 25.9 / 24.5 / 23.8 ms per 16 spp at 24 / 40 / 48
+#endif
+#define PBRS_LONG_WALK_HEIGHT 12u    // a mesh whose BLAS is at least this high makes the scene's walks "long"
 #ifndef PBRS_CHUNK_MAX
 #define PBRS_CHUNK_MAX 512u
 #endif
@@ -279,7 +286,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
-        if (__popcll(live) < PBRS_REFILL_BELOW) {
+        if ((uint32_t)__popcll(live) < S.refill_below) {
             if (walk.mode == PBRS_WALK_DONE) {  // finished walks are retired in batches, at refill time
                 const Hit& h = walk.best;
                 nhit += h.inst != 0xffffffffu ? 1u : 0u;
@@ -698,7 +705,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
-        if (__popcll(live) < PBRS_REFILL_BELOW) {
+        if ((uint32_t)__popcll(live) < S.refill_below) {
             if (walk.mode == PBRS_WALK_DONE) {
                 const bool occluded = walk.occluded;
                 const uint32_t slot = item & 0x3fffffffu, r = item >> 31;

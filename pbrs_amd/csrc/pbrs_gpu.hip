@@ -612,6 +612,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         S.fast_slab = ok ? 1u : 0u;
     }
     S.world = c->world;
+    S.refill_below = max_blas_height >= PBRS_LONG_WALK_HEIGHT ? PBRS_REFILL_BELOW_LONG : PBRS_REFILL_BELOW_SHORT;
     const uint32_t flat_feature = S.n_flat ? PBRS_FEAT_FLAT_TLAS : 0u;
     S.features = flat_feature;
     for (uint32_t i = 0; i < d->n_instances; ++i) {
