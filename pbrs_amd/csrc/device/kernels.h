@@ -146,10 +146,10 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 // its four divisions is the longest step); any-hit walks end at the first hit, where waiting at a boundary costs more
 // than it saves.
 #ifndef PBRS_EXT_XFER_MIN
-#define PBRS_EXT_XFER_MIN 12
+#define PBRS_EXT_XFER_MIN 8
 #endif
 #ifndef PBRS_EXT_LEAF_MIN
-#define PBRS_EXT_LEAF_MIN 14
+#define PBRS_EXT_LEAF_MIN 10
 #endif
 #ifndef PBRS_SHD_XFER_MIN
 #define PBRS_SHD_XFER_MIN 2
