@@ -144,7 +144,11 @@ typedef struct pbrs_material {
     uint32_t first_bxdf;
     uint32_t flags; /* PBRS_MATERIAL_TEXTURED: some lobe has tex != 0 */
     uint32_t vis_class; /* palette entry of material_visualizer for `Material::summary()`, src/directlighting.rs:247-259 */
-    uint32_t pad;
+    /* 1 + index of a pbrs_bxdf record (outside the material's lobe list) whose albedo / tex hold the colour that
+     * `Material::scatter` returns where it is a constant of the material — Lambertian albedo (possibly a texture), Mirror
+     * albedo, Plastic diffuse, Dielectric transmit (material/src/lib.rs:163-177, :224-228, :427-432, :246-264) — for
+     * normal_visualizer; 0 = not provided (PBRS_INTEGRATOR_NORMALS is then refused) */
+    uint32_t vis_bxdf;
 } pbrs_material;
 #define PBRS_MATERIAL_TEXTURED 1u
 
@@ -278,6 +282,11 @@ typedef struct pbrs_render_params {
  * pixel (`shoot_ray(row, col, (0.0, 0.0))`), a palette colour per kind of material at the first hit, a grey checker of
  * the ray direction where nothing is hit.  strata must be 1 x 1; max_depth is ignored (the reference passes 0). */
 #define PBRS_INTEGRATOR_MATERIALS 2u
+/* normal_visualizer, src/directlighting.rs:273-289 (`--visualize-normals`): one un-jittered ray per pixel,
+ * (albedo of `mtl.scatter(-ray.dir, &hit)` + hit.normal) * 0.5, the environment where nothing is hit.  `scatter` is
+ * `todo!()` for Glossy, Uber, Substrate and Fourier: their albedo counts as black.  Dielectric::scatter draws one random
+ * number: the pixel's RNG stream supplies it (first draw after the two of the unused jitter).  strata must be 1 x 1. */
+#define PBRS_INTEGRATOR_NORMALS 3u
 
 /* Renders a tile; replaces src/main.rs:192-231 for the rows/cols of the tile.  `rgb_out` is
  * w*h*3 floats, row-major.  _host writes to caller-owned host memory (one D2H copy at the end);

@@ -112,12 +112,12 @@ class OracleScene:
 
     def render(self, strata_x, strata_y, depth, seed, tile=None, nthreads=None, integrator="path"):
         """integrator: "path" (src/pathintegrator.rs), "direct" (direct_lighting_integrator, src/directlighting.rs:14-47) or
-        "materials" (material_visualizer, :234-271; strata 1 x 1)."""
+        "materials" / "normals" (material_visualizer :234-271, normal_visualizer :273-289; strata 1 x 1)."""
         x0, y0, w, h = tile or (0, 0, self.width, self.height)
         out = np.empty((h, w, 3), dtype=np.float32)
         st = Stats()
         nthreads = nthreads or os.cpu_count() or 1
-        kind = {"path": 0, "direct": 1, "materials": 2}[integrator]
+        kind = {"path": 0, "direct": 1, "materials": 2, "normals": 3}[integrator]
         rc = lib().oracle_render_tile_integrator(self._h, x0, y0, w, h, strata_x, strata_y, depth, seed, nthreads, kind, out.ctypes.data,
                                                  C.addressof(st))
         assert rc == 0

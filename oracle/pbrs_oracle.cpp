@@ -357,6 +357,59 @@ static Color material_visualizer(const Scene& scene, Ray ray) {
     int parity = (int)((uint32_t)pn_f32_to_i32(pn_floor(ray.dir.x * 50.0f)) + (uint32_t)pn_f32_to_i32(pn_floor(ray.dir.y * 50.0f)));
     return parity % 2 == 0 ? gray(0.9f) : gray(0.7f);
 }
+// normal_visualizer (src/directlighting.rs:273-289): (albedo of `mtl.scatter(-ray.dir, &hit)` + hit.normal) * 0.5, the
+// environment where nothing is hit.  `scatter` per material: material/src/lib.rs:163-177 (Lambertian), :192-199 (Metal),
+// :224-228 (Mirror), :246-264 (Dielectric; its one `rand::random::<f32>()` is drawn from `rng`), :282-286 (DiffuseLight),
+// :427-432 (Plastic); Glossy :213-215, Uber :314-316, Substrate :390-392 and Fourier :463-465 are `todo!()`: counted as a
+// panic, the pixel is black.  The directions `scatter` also draws do not reach the returned colour.
+static Color normal_visualizer(const Scene& scene, Ray ray, uint64_t* rng) {
+    auto c3 = [](const float* q) { return Color{q[0], q[1], q[2]}; };
+    Hit h;
+    REF_COUNT(closest_rays);
+    if (!scene.tlas->intersect(ray, &h)) return scene.eval_env_light(ray);
+    REF_COUNT(shade_events);
+    const Interaction& isect = h.isect;
+    const Material& m = *h.inst->mtl;
+    const float* p = m.spec.p;
+    const Vec3 wi_in = -ray.dir;
+    Color albedo = black();
+    switch (m.spec.kind) {
+        case PBRS_MTL_LAMBERTIAN: albedo = m.tex[0] ? m.tex[0]->value(isect.u, isect.v, isect.pos) : c3(p); break;
+        case PBRS_MTL_METAL: albedo = fresnel_conductor(c3(p), c3(p + 3)).eval(pn_abs(dot(isect.normal, wi_in))); break;
+        case PBRS_MTL_MIRROR: albedo = c3(p); break;
+        case PBRS_MTL_PLASTIC: albedo = c3(p); break;  // self.diffuse
+        case PBRS_MTL_DIFFUSE_LIGHT: break;
+        case PBRS_MTL_DIELECTRIC: {
+            const float ior = p[0];
+            const Color reflect_c = c3(p + 1), transmit_c = c3(p + 4);
+            Vec3 wi = hat(wi_in);
+            Vec3 outward;
+            float ratio, cosine;
+            if (dot(isect.normal, wi) < 0.0f) {
+                outward = -isect.normal;
+                ratio = ior;
+                cosine = -dot(isect.normal, wi);
+            } else {
+                outward = isect.normal;
+                ratio = 1.0f / ior;
+                cosine = dot(isect.normal, wi);
+            }
+            Vec3 wt;
+            float reflect_pr = 1.0f;
+            albedo = reflect_c;
+            if (refract(outward, wi, ratio, &wt)) {
+                float r0 = (1.0f - ior) / (1.0f + ior);  // schlick, :477-481
+                r0 = r0 * r0;
+                reflect_pr = r0 + (1.0f - r0) * pn_powi(1.0f - cosine, 5);
+                albedo = transmit_c;
+            }
+            if (pn_rng_f32(rng) < reflect_pr) albedo = reflect_c;
+            break;
+        }
+        default: REF_ASSERT(false && "Material::scatter: todo!()"); break;
+    }
+    return (albedo + Color{isect.normal.x, isect.normal.y, isect.normal.z}) * 0.5f;
+}
 // direct_lighting_integrator (:14-47): emitters return their emission; everything else the one-light estimate plus one
 // level of perfect-specular reflection/refraction followed by the debug integrator.
 static Color direct_lighting_integrator(const Scene& scene, Ray ray, int depth, uint64_t* rng) {
@@ -426,12 +479,12 @@ int oracle_render_tile(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_
 }
 
 // `integrator`: 0 = path_integrator (src/pathintegrator.rs), 1 = direct_lighting_integrator (src/directlighting.rs:14-47),
-// 2 = material_visualizer (:234-271; strata 1 x 1, the ray goes through the pixel's corner: `shoot_ray(row, col, (0.0, 0.0))`,
-// src/main.rs:170); all fit the reference's seam `fn(&Scene, Ray, i32) -> Color` (src/main.rs:160-187).
+// 2 = material_visualizer (:234-271), 3 = normal_visualizer (:273-289) — both with strata 1 x 1, the ray through the pixel's
+// corner: `shoot_ray(row, col, (0.0, 0.0))`, src/main.rs:170; all fit the reference's seam `fn(&Scene, Ray, i32) -> Color` (src/main.rs:160-187).
 int oracle_render_tile_integrator(const oracle_scene* os, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t strata_x,
                                   uint32_t strata_y, uint32_t max_depth, uint64_t seed, uint32_t nthreads, uint32_t integrator,
                                   float* rgb_out, oracle_stats* stats_out) {
-    if (integrator > 2 || (integrator == 2 && (strata_x != 1 || strata_y != 1))) return -1;
+    if (integrator > 3 || (integrator >= 2 && (strata_x != 1 || strata_y != 1))) return -1;
     const Scene& scene = *os->scene;
     if (nthreads == 0) nthreads = 1;
     const uint32_t width = scene.camera.width;
@@ -454,13 +507,14 @@ int oracle_render_tile_integrator(const oracle_scene* os, uint32_t x0, uint32_t 
                     float r0 = pn_rng_f32(&rng), r1 = pn_rng_f32(&rng);
                     float jx = ((float)(i / strata_y) + r0) / (float)strata_x;
                     float jy = ((float)(i % strata_y) + r1) / (float)strata_y;
-                    if (integrator == 2) jx = jy = 0.0f;
+                    if (integrator >= 2) jx = jy = 0.0f;
                     Ray ray;
                     scene.camera.shoot_ray(row, col, jx, jy, &ray);
                     REF_COUNT(samples);
                     color_sum = color_sum + (integrator == 0   ? path_integrator(scene, ray, (int)max_depth, &rng, nullptr)
                                              : integrator == 1 ? direct_lighting_integrator(scene, ray, (int)max_depth, &rng)
-                                                               : material_visualizer(scene, ray));
+                                             : integrator == 2 ? material_visualizer(scene, ray)
+                                                               : normal_visualizer(scene, ray, &rng));
                 }
                 Color color = color_sum * (1.0f / (float)spp);  // scale_down_by, color.rs:90-95
                 float* px = rgb_out + 3 * ((size_t)ry * w + cx);

@@ -143,7 +143,7 @@ def gpu_lib():
     return _gpu
 
 
-INTEGRATORS = {"path": 0, "direct": 1, "materials": 2}  # PBRS_INTEGRATOR_*
+INTEGRATORS = {"path": 0, "direct": 1, "materials": 2, "normals": 3}  # PBRS_INTEGRATOR_*
 
 
 class LoadedScene:

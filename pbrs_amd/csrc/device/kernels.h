@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
     // src/main.rs:198-201 with msaa -> (strata_x, strata_y): i / msaa, i % msaa
     float jx = ((float)(i / rc.strata_y) + r0) / (float)rc.strata_x;
     float jy = ((float)(i % rc.strata_y) + r1) / (float)rc.strata_y;
-    if (rc.integrator == PBRS_INTEGRATOR_MATERIALS) jx = jy = 0.0f;  // `shoot_ray(row, col, (0.0, 0.0))`, src/main.rs:170
+    if (rc.integrator >= PBRS_INTEGRATOR_MATERIALS) jx = jy = 0.0f;  // the visualisers: `shoot_ray(row, col, (0.0, 0.0))`, src/main.rs:170
     // Camera::shoot_ray, camera.rs:65-77
     float x = (float)col + pn_fract(jx);
     float y = (float)row + pn_fract(jy);
@@ -397,6 +397,52 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                 L = gray(parity % 2 == 0 ? 0.9f : 0.7f);
             }
             emitter_hit = true;  // nothing below runs for this lane
+        } else if (INTEG == PBRS_INTEGRATOR_NORMALS) {  // normal_visualizer, src/directlighting.rs:273-289
+            if (!has_hit) {
+                L = env_eval(S, d);
+            } else {
+                const Isect is = reconstruct_isect(S, h, o, d);
+                const pbrs_bxdf& lobe0 = S.bxdfs[mat->first_bxdf];
+                const pbrs_bxdf& vis = S.bxdfs[mat->vis_bxdf - 1u];
+                f3 albedo = gray(0.0f);  // `let (_, albedo) = mtl.scatter(-ray.dir, &hit)`; black where scatter is todo!()
+                switch (mat->vis_class) {
+                    case 8:  // Lambertian, material/src/lib.rs:163-177
+                        albedo = vis.tex ? tex_value(S, (vis.tex & ~PBRS_BXDF_TEX_DROP_IF_BLACK) - 1u, is.u, is.v, is.pos) : ld3(vis.albedo);
+                        break;
+                    case 7:  // Metal :192-199: Fresnel::conductor(eta, k).eval(|n . wi|), wi = -ray.dir as it is
+                        albedo = fresnel_eval(lobe0, pn_abs(dot(is.normal, -d)));
+                        break;
+                    case 5:  // Mirror :224-228
+                    case 0:  // Plastic :427-432
+                        albedo = ld3(vis.albedo);
+                        break;
+                    case 4: {  // Dielectric :246-264
+                        const float ior = lobe0.eta[1];
+                        const f3 wi = hat(-d);
+                        const float ndw = dot(is.normal, wi);
+                        const bool inside = ndw < 0.0f;
+                        const f3 outward = inside ? -is.normal : is.normal;
+                        const float ratio = inside ? ior : 1.0f / ior;
+                        const float cosine = inside ? -ndw : ndw;
+                        f3 wt;
+                        const bool transmits = refract3(outward, wi, ratio, wt);
+                        float reflect_pr = 1.0f;
+                        albedo = ld3(lobe0.albedo);  // self.reflect
+                        if (transmits) {
+                            float r0 = (1.0f - ior) / (1.0f + ior);  // schlick, :477-481
+                            r0 = r0 * r0;
+                            reflect_pr = r0 + (1.0f - r0) * pn_powi(1.0f - cosine, 5);
+                            albedo = ld3(vis.albedo);  // self.transmit
+                        }
+                        uint64_t rng = at(st.rng, slot);
+                        if (pn_rng_f32(&rng) < reflect_pr) albedo = ld3(lobe0.albedo);
+                        break;
+                    }
+                    default: break;  // DiffuseLight: black (:282-286); Glossy / Uber / Substrate / Fourier: todo!()
+                }
+                L = (albedo + is.normal) * 0.5f;
+            }
+            emitter_hit = true;
         } else if (INTEG == PBRS_INTEGRATOR_PATH) {
             if (bounce == 0 || specular_bounce) {  // pathintegrator.rs:19-22
                 f3 e = has_hit ? ld3(mat->emission) : env_eval(S, d);

@@ -400,6 +400,21 @@ void flatten_material(const pbrs_material_spec& m, pbrs_material* out, std::vect
         default: break;
     }
     out->n_bxdfs = (uint32_t)bx.size() - out->first_bxdf;
+    // pbrs_material::vis_bxdf: the colour `scatter` returns, for normal_visualizer (src/directlighting.rs:283)
+    const float black[3] = {0.0f, 0.0f, 0.0f};
+    pbrs_bxdf vis = bx_lambert(black);
+    switch (m.kind) {
+        case PBRS_MTL_LAMBERTIAN:  // `self.albedo.value(isect.uv, isect.pos)`, :177
+            set3(vis.albedo, p);
+            vis.tex = m.tex[0];
+            break;
+        case PBRS_MTL_MIRROR: set3(vis.albedo, p); break;          // :227
+        case PBRS_MTL_PLASTIC: set3(vis.albedo, p); break;         // `self.diffuse`, :431
+        case PBRS_MTL_DIELECTRIC: set3(vis.albedo, p + 4); break;  // `self.transmit` (`reflect` is the lobe's colour), :256
+        default: break;  // Metal: Fresnel of the lobe; DiffuseLight: black; the others never return
+    }
+    bx.push_back(vis);
+    out->vis_bxdf = (uint32_t)bx.size();
 }
 
 }  // namespace
@@ -641,7 +656,6 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
                                                        /* substrate */ 1};
             const uint32_t kind = spec->materials[m].kind;
             pm.vis_class = kind <= PBRS_MTL_SUBSTRATE ? palette_of_kind[kind] : 9u;
-            pm.pad = 0;
         }
         if (pm.n_bxdfs > PBRS_MAX_BXDFS) {
             g_error = "material with more than PBRS_MAX_BXDFS lobes";

@@ -63,6 +63,7 @@ struct pbrs_ctx {
     pbrs_stats pending{};
     bool pending_counters = false, pending_times = false;
     bool textured = false;  // the uploaded scene evaluates non-Solid textures: k_shade<.., true>
+    bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
     uint64_t pending_closest = 0;
 };
 
@@ -187,9 +188,11 @@ int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* 
     }
     if (p->strata_x == 0 || p->strata_y == 0) return fail(c, PBRS_E_INVALID, "zero strata");
     if (p->max_depth > kMaxDepth) return fail(c, PBRS_E_LIMIT, "max_depth above 64");
-    if (p->integrator > PBRS_INTEGRATOR_MATERIALS) return fail(c, PBRS_E_INVALID, "unknown integrator");
-    if (p->integrator == PBRS_INTEGRATOR_MATERIALS && (p->strata_x != 1 || p->strata_y != 1))
-        return fail(c, PBRS_E_INVALID, "the material visualiser takes one un-jittered ray per pixel (strata 1 x 1)");
+    if (p->integrator > PBRS_INTEGRATOR_NORMALS) return fail(c, PBRS_E_INVALID, "unknown integrator");
+    if (p->integrator >= PBRS_INTEGRATOR_MATERIALS && (p->strata_x != 1 || p->strata_y != 1))
+        return fail(c, PBRS_E_INVALID, "a visualiser takes one un-jittered ray per pixel (strata 1 x 1)");
+    if (p->integrator == PBRS_INTEGRATOR_NORMALS && !c->has_vis_records)
+        return fail(c, PBRS_E_INVALID, "the scene's materials carry no pbrs_material::vis_bxdf records");
     if ((uint64_t)p->w * p->h > (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile above 2^28 pixels");
     // queue entries keep two flag bits next to the slot index
     if ((uint64_t)p->w * p->h * auto_samples_per_pass(c, p) >= (1ull << 30)) return fail(c, PBRS_E_LIMIT, "tile x samples_per_pass above 2^30 paths");
@@ -317,7 +320,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     const size_t lds = lds_bytes(c);
     // the direct-lighting integrator is at most two rays deep whatever `depth` says (directlighting.rs:15-17, :36, :49)
     const uint32_t n_bounces = rc.integrator == PBRS_INTEGRATOR_DIRECT      ? (rc.max_depth ? 2u : 0u)
-                               : rc.integrator == PBRS_INTEGRATOR_MATERIALS ? 1u  // one cast, no lights (directlighting.rs:247)
+                               : rc.integrator >= PBRS_INTEGRATOR_MATERIALS ? 1u  // the visualisers: one cast, no lights
                                                                             : rc.max_depth;
     for (uint32_t b = 0; b < n_bounces; ++b) {
         const uint32_t* qin = b == 0 ? nullptr : q[b & 1];
@@ -332,6 +335,8 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
             const bool direct = rc.integrator == PBRS_INTEGRATOR_DIRECT;
             if (rc.integrator == PBRS_INTEGRATOR_MATERIALS) {
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false);
+            } else if (rc.integrator == PBRS_INTEGRATOR_NORMALS) {
+                PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_NORMALS, false);
             } else if (c->textured) {  // some material evaluates a non-Solid texture per hit
                 if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true);
                 else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true);
@@ -386,7 +391,7 @@ int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params*
     HIPCHK(c, hipGetLastError());
     c->pending.passes = passes;
     c->pending.launches_extend = c->pending.launches_shade = c->pending.launches_shadow =
-        passes * (p->integrator == PBRS_INTEGRATOR_DIRECT ? (p->max_depth ? 2u : 0u) : p->integrator == PBRS_INTEGRATOR_MATERIALS ? 1u : p->max_depth);
+        passes * (p->integrator == PBRS_INTEGRATOR_DIRECT ? (p->max_depth ? 2u : 0u) : p->integrator >= PBRS_INTEGRATOR_MATERIALS ? 1u : p->max_depth);
     return PBRS_OK;
 }
 
@@ -519,9 +524,12 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         if (in.shape_kind == PBRS_SHAPE_MESH ? in.blas_root >= d->n_blas_nodes : (in.shape_kind == PBRS_SHAPE_TRIANGLE && in.blas_root >= d->n_triangles))
             return fail(c, PBRS_E_INVALID, "instance blas_root out of range");
     }
+    bool vis_records = d->n_materials > 0;
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const pbrs_material& m = d->materials[i];
         if (m.n_bxdfs > PBRS_MAX_BXDFS || (uint64_t)m.first_bxdf + m.n_bxdfs > d->n_bxdfs) return fail(c, PBRS_E_INVALID, "material lobes out of range");
+        if (m.vis_bxdf > d->n_bxdfs) return fail(c, PBRS_E_INVALID, "material visualiser record out of range");
+        if (m.vis_bxdf == 0) vis_records = false;
     }
     bool textured = false;
     for (uint32_t i = 0; i < d->n_bxdfs; ++i) {
@@ -625,6 +633,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     }
     c->S = S;
     c->textured = textured;
+    c->has_vis_records = vis_records;
     c->stack_depth = depth;
     c->has_scene = true;
     size_t lds = lds_bytes(c);

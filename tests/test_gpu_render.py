@@ -239,6 +239,30 @@ def _material_zoo():
 
 
 @pytest.mark.parametrize("cfg", ["zoo", "c3", "c5"])
+def test_normal_visualizer_matches_oracle(gpu_ctx, cfg):
+    """`--visualize-normals` (src/directlighting.rs:273-289): (the colour `Material::scatter` returns + the hit's normal) / 2
+    per pixel, the environment where nothing is hit.  Covers every `scatter` that returns (a textured Lambertian among
+    them), the Dielectric's random choice between its two colours (drawn from the pixel's RNG stream), and the four
+    materials whose `scatter` is `todo!()` (their colour counts as black)."""
+    if cfg == "zoo":
+        sb = _material_zoo()
+        from pbrs_amd.spec import Transform
+        sb.instance(sb.sphere((0, 0, 0), 0.45), sb.lambertian(sb.checker((0.9, 0.2, 0.2), (0.1, 0.1, 0.8))), Transform.translater((2.0, -0.6, 0.0)))
+        sb.env_sky(pbrs_amd.spec.ENV_DUSK)
+    else:
+        sb = scenes.build_config(cfg, width=96, height=54)[0]
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    img, st = gpu_ctx.render(1, 1, 0, 5, integrator="normals", counters=True)
+    ref, ost = OracleScene(sb).render(1, 1, 0, 5, integrator="normals")
+    assert (bits(img) == bits(ref)).all()
+    assert st["closest_rays"] == ost["closest_rays"] == img.shape[0] * img.shape[1] and st["shadow_rays"] == 0
+    if cfg == "zoo":
+        assert ost["panics"] > 100 and len(np.unique(img.reshape(-1, 3), axis=0)) > 1000
+    with pytest.raises(pbrs_amd.PbrsError):
+        gpu_ctx.render(1, 2, 0, 1, integrator="normals")
+
+
+@pytest.mark.parametrize("cfg", ["zoo", "c3", "c5"])
 def test_material_visualizer_matches_oracle(gpu_ctx, cfg):
     """`--visualize-materials` (src/main.rs:166-187, src/directlighting.rs:234-271): one un-jittered ray per pixel, a
     palette colour per kind of material, a grey checker of the ray direction where nothing is hit."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Renders a pbrt-v3 scene file on the GPU and writes an EXR (or PNG):  tools/render_pbrt.py scene.pbrt out.exr [msaa] [depth] [path|direct]"""
+"""Renders a pbrt-v3 scene file on the GPU and writes an EXR (or PNG):  tools/render_pbrt.py scene.pbrt out.exr [msaa] [depth] [path|direct|materials|normals]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pbrs_amd
@@ -11,7 +11,7 @@ integrator = sys.argv[5] if len(sys.argv) > 5 else "path"
 ls = pbrs_amd.load_pbrt(scene)
 ctx = pbrs_amd.Context(0)
 ctx.upload(pbrs_amd.HostScene(ls))
-if integrator == "materials":  # --visualize-materials of the reference (src/main.rs:183-185): one ray per pixel
+if integrator in ("materials", "normals"):  # --visualize-materials / --visualize-normals (src/main.rs:180-185): one ray per pixel
     msaa = 1
 img, st = ctx.render(msaa, msaa, depth, 1, integrator=integrator, timing=True)
 pbrs_amd.write_image(out, img)
