@@ -4,10 +4,13 @@
     python bench.py --gpus N --steps K --warmup W          (N = 1: plain process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one whole frame of the workload: every rank renders its interleaved row bands of the frame
-on its own GPU (scene already resident in HBM), copies them to the host and rank 0 gathers them into
-the frame buffer (host-side gather over gloo; no RCCL: pixels are independent).
-Total work is fixed as N grows, so scaling is reported as "strong".
+The timed workload (`value`, `config.workload`) is the one BASELINE.json's north star quotes its targets on: C4 =
+configs[3], the procedural 1 048 576-triangle mesh, 1920x1080, 512 spp, path depth 8, at full size — it fits one GPU,
+and it is the same workload for every N so that the N = 1 value of a scaling run agrees with the single-GPU bench.
+A step is one whole frame: every rank renders its interleaved row bands of the frame on its own GPU (scene already
+resident in HBM), copies them to the host and rank 0 assembles the frame (shared-memory frame, or a gloo gather; no RCCL:
+pixels are independent).  Total work is fixed as N grows, so scaling is reported as "strong".
+At N = 1 the same run also times C2 and C3 at full size (fewer steps) and reports them under `other_configs`.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -22,13 +25,18 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+DEFAULT_CONFIG = "c4"
+CPU_SAMPLES = {"c1": (256, 256, 4), "c2": (512, 512, 4), "c3": (512, 512, 4), "c4": (960, 540, 4), "c5": (960, 540, 4)}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", help="c1..c5 (BASELINE.json configs[0..4]); default c2 = configs[1]")
+    ap.add_argument("--config", default=DEFAULT_CONFIG, help="c1..c5 (BASELINE.json configs[0..4]); default c4 = the north-star workload")
+    ap.add_argument("--also", default=None, help="comma-separated configs timed after the main one at N = 1 (default: c2,c3 when --config is c4)")
+    ap.add_argument("--also-steps", type=int, default=2)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--strata", type=int, nargs=2, default=None, metavar=("SX", "SY"))
@@ -38,7 +46,9 @@ def parse():
     ap.add_argument("--integrator", default="path", choices=["path", "direct"],
                     help="path = src/pathintegrator.rs (the BASELINE metric); direct = direct_lighting_integrator (src/directlighting.rs:14-47)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, nargs=3, default=None, metavar=("W", "H", "MSAA"), help="CPU baseline sample (default 384 384 4)")
+    ap.add_argument("--cpu-sample", type=int, nargs=3, default=None, metavar=("W", "H", "MSAA"), help="CPU baseline sample (default per config)")
+    ap.add_argument("--allow-shared-gpus", action="store_true",
+                    help="rehearsal only: let more ranks than visible GPUs share devices round-robin (the JSON then says so)")
     return ap.parse_args()
 
 
@@ -78,157 +88,229 @@ def cpu_baseline(config_name, depth, seed, sample, integrator="path"):
     }
 
 
+def device_identity(torch, ordinal):
+    p = torch.cuda.get_device_properties(ordinal)
+    ident = {"ordinal": ordinal, "name": p.name}
+    for k in ("pci_bus_id", "pci_device_id", "pci_domain_id", "uuid"):
+        if hasattr(p, k):
+            ident[k] = str(getattr(p, k))
+    return ident
+
+
+class Workload:
+    """One BASELINE config resident on this rank's GPU, rendered frame by frame."""
+
+    def __init__(self, args, config, ctx, torch, dist, dev, world, rank):
+        import pbrs_amd
+        from pbrs_amd import scenes, tiling
+        self.args, self.name, self.ctx, self.torch, self.dist, self.world, self.rank = args, config, ctx, torch, dist, world, rank
+        self.tiling = tiling
+        sb, cfg = scenes.build_config(config, width=args.width, height=args.height)
+        if args.strata:
+            cfg["strata_x"], cfg["strata_y"] = args.strata
+        if args.depth:
+            cfg["depth"] = args.depth
+        self.W, self.H, self.sx, self.sy, self.depth = cfg["width"], cfg["height"], cfg["strata_x"], cfg["strata_y"], cfg["depth"]
+        self.full_size = (self.W, self.H, self.sx, self.sy, self.depth) == tuple(scenes.CONFIGS[config][2:7]) and args.integrator == "path"
+        self.hs = pbrs_amd.HostScene(sb)
+        ctx.upload(self.hs)  # scene resident in HBM before any timed region
+        self.my_rows = tiling.packed_height(self.H, world, rank)
+        self.out_dev = torch.empty((max(self.my_rows, 1), self.W, 3), dtype=torch.float32, device=dev)
+        self.out_host = torch.empty((max(self.my_rows, 1), self.W, 3), dtype=torch.float32).pin_memory()
+        self.bands = (tiling.BAND_ROWS, world, rank) if world > 1 else None
+        # one node: the ranks write their rows into a frame in shared memory (no data through gloo); otherwise gloo gather
+        self.shared = tiling.SharedFrame.create(self.W, self.H, world, rank) if world > 1 else None
+        self.gather_s = 0.0
+
+    def step(self, timing=False, counters=False):
+        a = self.args
+        if self.my_rows:
+            self.ctx.render_device(self.out_dev.data_ptr(), self.sx, self.sy, self.depth, a.seed, tile=(0, 0, self.W, self.my_rows), bands=self.bands,
+                                   samples_per_pass=a.samples_per_pass, timing=timing, counters=counters, integrator=a.integrator)
+        self.torch.cuda.synchronize()
+        t = time.perf_counter()
+        self.out_host.copy_(self.out_dev)
+        if self.shared is not None:
+            frame = self.shared.publish(self.out_host.numpy()[:self.my_rows])
+        else:
+            frame = self.tiling.gather_frame(self.out_host.numpy()[:self.my_rows], self.W, self.H, self.world, self.rank)
+        self.gather_s += time.perf_counter() - t
+        return frame
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, steps, warmup):
+        """W untimed frames, then exactly `steps` frames between barriers; returns rank 0's report (None elsewhere)."""
+        from pbrs_amd import roofline
+        torch, dist, world, rank = self.torch, self.dist, self.world, self.rank
+        # the first frame allocates the path state (tens of GB): it is never a timed one, whatever --warmup says
+        for _ in range(max(warmup, 1)):
+            self.step()
+        self.barrier()
+        self.gather_s = 0.0
+        t0 = time.perf_counter()
+        stage_ms, launches = None, None
+        for _ in range(steps):
+            self.step(timing=True)
+            st = self.ctx.collect_stats() if self.my_rows else None
+            if st is not None:
+                if stage_ms is None:
+                    stage_ms = {k: 0.0 for k in st if k.startswith("ms_")}
+                    launches = {k: 0 for k in st if k.startswith("launches_")}
+                for k in stage_ms:
+                    stage_ms[k] += st[k]
+                for k in launches:
+                    launches[k] += st[k]
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        gather_ms = self.gather_s / steps * 1e3
+        if world > 1:
+            t = torch.tensor([elapsed, gather_ms], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, gather_ms = float(t[0].item()), float(t[1].item())
+
+        # Untimed: instrumented frame for ray / node / primitive counts (deterministic, equal to the timed work).
+        frame = self.step(counters=True)
+        cst = self.ctx.collect_stats() if self.my_rows else None
+        counts = np.array([cst["closest_rays"], cst["shadow_rays"], cst["samples"], cst["invalid_samples"]] if cst else [0, 0, 0, 0], dtype=np.float64)
+        if world > 1:
+            tc = torch.from_numpy(counts)
+            dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+            counts = tc.numpy()
+        if rank != 0:
+            return None
+
+        W, H, sx, sy, depth, spp = self.W, self.H, self.sx, self.sy, self.depth, self.sx * self.sy
+        samples_per_step = float(W) * H * spp
+        assert counts[2] == samples_per_step, (counts, samples_per_step)
+        rays_per_step = counts[0] + counts[1]
+        times = {k: v / steps for k, v in stage_ms.items()}
+        times.update({k: v // steps for k, v in launches.items()})
+        # HBM bytes per launch cannot be collected in-process (rocprofv3 owns the counters): the last measured figures for
+        # this workload are read from profiles/ (tools/round_artifacts.sh -> tools/traffic_from_pmc.py), full-size runs only.
+        traffic_doc, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", f"latest_traffic_{self.name}.json")
+        if os.path.exists(tpath) and world == 1 and self.full_size and not self.args.samples_per_pass:
+            with open(tpath) as f:
+                traffic_doc = json.load(f)
+            traffic_src = os.path.relpath(tpath, ROOT)
+        rep = roofline.stage_report(cst, times, scene_nbytes=self.hs.nbytes, traffic_doc=traffic_doc)
+        dom_name, dom = roofline.dominant(rep)
+        trav = roofline.traversal(rep)
+        for r in list(rep.values()) + [trav]:
+            assert r["frac"] <= 1.0, f"roofline fraction above 1: {r}"  # a figure above the HBM peak is not an HBM figure
+        return {
+            "value": samples_per_step * steps / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "steps": steps,
+            "ms_per_step": elapsed / steps * 1e3,
+            "config": {"workload": f"BASELINE configs[{int(self.name[1]) - 1}] ({self.name}): {W}x{H}, {spp} spp ({sx}x{sy} strata), "
+                                   f"path depth {depth}, frame tiled over {world} GPU(s) in interleaved {self.tiling.BAND_ROWS}-row bands",
+                       "scene": self.name, "width": W, "height": H, "spp": spp, "depth": depth, "seed": self.args.seed,
+                       "integrator": self.args.integrator, "scene_bytes_in_hbm": self.hs.nbytes, "full_size": self.full_size},
+            "mrays_per_s": rays_per_step * steps / elapsed / 1e6,
+            "rays_per_step": rays_per_step,
+            "invalid_samples": counts[3],
+            "frame_mean_radiance": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)],
+            "gather_ms": gather_ms,
+            "roofline": {
+                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["frac"], "traffic": dom["traffic_bytes_per_launch"], "traffic_source": traffic_src,
+                "bytes_per_launch": dom["queue_state_bytes_per_launch"] + dom["scene_miss_bytes_per_launch"],
+                "queue_state_bytes_per_launch": dom["queue_state_bytes_per_launch"], "scene_miss_bytes_per_launch": dom["scene_miss_bytes_per_launch"],
+                "scene_bytes_per_launch": dom["scene_bytes_per_launch"], "cache_work_rate_GBps": dom["cache_work_rate_GBps"],
+                "ms_per_launch": dom["ms_per_launch"], "launches_per_step": dom["launches"],
+                "note": "rank 0's kernels, the stage with the most time per frame; achieved = (queue/state bytes that must cross HBM, SURVEY.md §8d "
+                        "per-unit figures x units of one launch, + scene bytes that missed the caches) / HIP-event time per launch; scene misses "
+                        "and traffic = HBM bytes per launch from separate rocprofv3 TCC passes, measured offline, see profiles/; "
+                        "cache_work_rate prices every node / triangle visit at record size and is NOT an HBM figure",
+            },
+            "traversal": trav,
+            "stages_ms_per_step": times,
+            "stages": rep,
+        }
+
+    def close(self):
+        if self.shared is not None:
+            self.shared.close()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     import torch
     import torch.distributed as dist
 
     import pbrs_amd
-    from pbrs_amd import roofline, scenes, tiling
 
+    gpus_visible = torch.cuda.device_count()
+    if gpus_visible == 0:
+        sys.exit("bench.py: no GPU visible; the product path has no CPU fallback")
+    if local_world > gpus_visible and not args.allow_shared_gpus:
+        # a scaling line must never claim more GPUs than it ran on
+        sys.exit(f"bench.py: {local_world} ranks on this node but only {gpus_visible} GPU(s) visible; "
+                 f"pass --allow-shared-gpus for a rehearsal (the JSON line then reports the sharing)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)  # host-side barrier/gather only
-    # one rank per GPU; a rehearsal with more ranks than GPUs (development box) shares the devices round-robin
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    sb, cfg = scenes.build_config(args.config, width=args.width, height=args.height)
-    if args.strata:
-        cfg["strata_x"], cfg["strata_y"] = args.strata
-    if args.depth:
-        cfg["depth"] = args.depth
-    W, H, sx, sy, depth = cfg["width"], cfg["height"], cfg["strata_x"], cfg["strata_y"], cfg["depth"]
-    spp = sx * sy
-    hs = pbrs_amd.HostScene(sb)
-    ctx = pbrs_amd.Context(local_rank)
-    ctx.upload(hs)  # scene resident in HBM before any timed region
-
-    my_rows = tiling.packed_height(H, world, rank)
-    out_dev = torch.empty((max(my_rows, 1), W, 3), dtype=torch.float32, device=dev)
-    out_host = torch.empty((max(my_rows, 1), W, 3), dtype=torch.float32).pin_memory()
-    bands = (tiling.BAND_ROWS, world, rank) if world > 1 else None
-
-    # one node: the ranks write their rows into a frame in shared memory (no data through gloo); otherwise gloo gather
-    shared = tiling.SharedFrame.create(W, H, world, rank) if world > 1 else None
-
-    def step(timing=False, counters=False):
-        if my_rows:
-            ctx.render_device(out_dev.data_ptr(), sx, sy, depth, args.seed, tile=(0, 0, W, my_rows), bands=bands,
-                              samples_per_pass=args.samples_per_pass, timing=timing, counters=counters, integrator=args.integrator)
-        torch.cuda.synchronize()
-        out_host.copy_(out_dev)
-        if shared is not None:
-            return shared.publish(out_host.numpy()[:my_rows])
-        return tiling.gather_frame(out_host.numpy()[:my_rows], W, H, world, rank)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # the first frame allocates the path state (tens of GB): it is never a timed one, whatever --warmup says
-    for _ in range(max(args.warmup, 1)):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    stage_ms = None
-    for _ in range(args.steps):
-        step(timing=True)
-        st = ctx.collect_stats() if my_rows else None
-        if st is not None:
-            if stage_ms is None:
-                stage_ms = {k: 0.0 for k in st if k.startswith("ms_")}
-                launches = {k: 0 for k in st if k.startswith("launches_")}
-            for k in stage_ms:
-                stage_ms[k] += st[k]
-            for k in launches:
-                launches[k] += st[k]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    ordinal = local_rank % gpus_visible
+    torch.cuda.set_device(ordinal)
+    dev = torch.device("cuda", ordinal)
+    ident = device_identity(torch, ordinal)
+    idents = [ident]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
 
-    # Untimed: instrumented frame for ray / node / primitive counts (deterministic, equal to the timed work).
-    frame = step(counters=True)
-    cst = ctx.collect_stats() if my_rows else None
-    counts = np.array([cst["closest_rays"], cst["shadow_rays"], cst["samples"]] if cst else [0, 0, 0], dtype=np.float64)
-    if world > 1:
-        tc = torch.from_numpy(counts)
-        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
-        counts = tc.numpy()
+    ctx = pbrs_amd.Context(ordinal)
+    main_wl = Workload(args, args.config, ctx, torch, dist, dev, world, rank)
+    result = main_wl.measure(args.steps, args.warmup)
+    main_wl.close()
+
+    others = {}
+    also = args.also if args.also is not None else ("c2,c3" if args.config == DEFAULT_CONFIG and not (args.width or args.height or args.strata or args.depth) else "")
+    if world == 1:
+        for name in [c for c in also.split(",") if c]:
+            wl = Workload(args, name, ctx, torch, dist, dev, world, rank)
+            r = wl.measure(args.also_steps, 1)
+            wl.close()
+            others[name] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "mrays_per_s", "config", "roofline", "traversal", "stages_ms_per_step")}
 
     if rank == 0:
-        samples_per_step = float(W) * H * spp
-        assert counts[2] == samples_per_step, (counts, samples_per_step)
-        rays_per_step = counts[0] + counts[1]
-        ms_per_step = elapsed / args.steps * 1e3
-        value = samples_per_step * args.steps / elapsed / 1e6
-        times = dict(stage_ms)
-        times.update(launches)
-        rep = roofline.stage_report(cst, {k: (v / args.steps if k.startswith("ms_") else v // args.steps) for k, v in times.items()})
-        dom_name, dom = roofline.dominant(rep)
-        # HBM bytes per launch from the PMC counters cannot be collected in-process (rocprofv3 owns the counters); the
-        # last measured figure for this workload, if any, is read from profiles/ (tools/traffic_from_pmc.py).
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", f"latest_traffic_{args.config}.json")
-        full_size = (W, H, sx, sy, depth) == tuple(scenes.CONFIGS[args.config][2:7]) and args.integrator == "path"  # as when it was measured
-        if os.path.exists(tpath) and world == 1 and full_size and not args.samples_per_pass:
-            with open(tpath) as f:
-                measured = json.load(f)["kernels"]
-            # the uninstrumented instantiation(s) of the dominant kernel, e.g. "k_extend<false, 4u>", "k_shade<0u, false>"
-            tk = [v for k, v in measured.items()
-                  if k == dom["kernel"] or (k.startswith(dom["kernel"] + "<") and not k.startswith(dom["kernel"] + "<true"))]
-            if tk:
-                traffic = sum(v["hbm_total"] * v["launches"] for v in tk) / sum(v["launches"] for v in tk)
-                traffic_src = os.path.relpath(tpath, ROOT)
-        traversal_ms = (stage_ms["ms_extend"] + stage_ms["ms_shadow"]) / args.steps
-        traversal_bytes = roofline.extend_bytes(cst) + roofline.shadow_bytes(cst)
-        result = {
+        distinct = {d.get("uuid") or d.get("pci_bus_id") or d["ordinal"] for d in idents}  # one node: ranks on one device share its identity
+        line = {
             "metric": "Msamples/s",
-            "value": value,
+            "value": result["value"],
             "unit": "Msamples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": result["ms_per_step"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{int(args.config[1]) - 1}] ({args.config}): {W}x{H}, {spp} spp ({sx}x{sy} strata), "
-                                   f"path depth {depth}, frame tiled over {world} GPU(s) in interleaved {tiling.BAND_ROWS}-row bands",
-                       "scene": args.config, "width": W, "height": H, "spp": spp, "depth": depth, "seed": args.seed,
-                       "integrator": args.integrator},
-            "mrays_per_s": rays_per_step * args.steps / elapsed / 1e6,
-            "rays_per_step": rays_per_step,
-            "frame_mean_radiance": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)],
-            "roofline": {
-                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["achieved_GBps"] / roofline.HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "bytes_per_launch": dom["bytes_per_launch"], "ms_per_launch": dom["ms_per_launch"], "launches_per_step": dom["launches"],
-                "note": "rank 0's kernels; achieved = algorithmic bytes (SURVEY.md §8d) / HIP-event time; traffic = HBM bytes per launch from separate "
-                        "rocprofv3 FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled per the gfx950 guide), measured offline, see profiles/",
-            },
-            "traversal": {"achieved": traversal_bytes / (traversal_ms * 1e-3) / 1e9 if traversal_ms > 0 else 0.0, "unit": "GB/s",
-                          "frac": (traversal_bytes / (traversal_ms * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS) if traversal_ms > 0 else 0.0,
-                          "kernels": "k_extend + k_shadow"},
-            "stages_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
-            "stages": rep,
+            "config": result["config"],
+            "gpus_visible": gpus_visible,
+            "gpus_used": len(distinct),
+            "shared_gpus": len(distinct) < world,
+            "devices": idents,
         }
+        for k in ("mrays_per_s", "rays_per_step", "invalid_samples", "frame_mean_radiance", "gather_ms", "roofline", "traversal", "stages_ms_per_step", "stages"):
+            line[k] = result[k]
+        if others:
+            line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
-            sample = tuple(args.cpu_sample) if args.cpu_sample else (384, 384, 4)
-            result["cpu_baseline"] = cpu_baseline(args.config, depth, args.seed, sample, args.integrator)
-        print(json.dumps(result))
-    if shared is not None:
-        shared.close()
+            sample = tuple(args.cpu_sample) if args.cpu_sample else CPU_SAMPLES[args.config]
+            line["cpu_baseline"] = cpu_baseline(args.config, result["config"]["depth"], args.seed, sample, args.integrator)
+        print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

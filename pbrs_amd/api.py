@@ -204,6 +204,14 @@ class HostScene:
     def stack_depth(self):
         return host_lib().pbrs_host_scene_stack_depth(self._h)
 
+    @property
+    def nbytes(self):
+        """Bytes of the flattened scene as it sits in HBM (record sizes of include/pbrs_gpu.h)."""
+        d = self.desc
+        return (32 * (d.n_tlas_nodes + d.n_blas_nodes) + 128 * d.n_instances + 48 * d.n_shapes + 32 * d.n_meshes +
+                (48 + 64) * d.n_triangles + 32 * d.n_materials + 64 * d.n_bxdfs + 64 * d.n_area_lights + 32 * d.n_delta_lights +
+                48 * d.n_textures + 4 * (d.n_tex_floats + d.n_tex_words))
+
     def nodes(self, which="tlas"):
         n, p = (self.desc.n_tlas_nodes, self.desc.tlas_nodes) if which == "tlas" else (self.desc.n_blas_nodes, self.desc.blas_nodes)
         if n == 0 or not p:

@@ -64,24 +64,33 @@ def gather_frame(share, width, height, world, rank, group=None, band_rows=BAND_R
 
 
 class SharedFrame:
-    """The frame buffer of a one-node job in POSIX shared memory: every rank writes its own rows in place and bumps its
-    sequence number in the same mapping; the frame is complete when every rank's number has reached it — nothing is sent.
+    """The frame buffers of a one-node job in POSIX shared memory: every rank writes its own rows in place and bumps its
+    sequence number in the same mapping; frame n is complete when every rank's number has reached n — nothing is sent.
     (`gather_frame` moves 12 B per pixel through gloo's TCP loopback, ≈30 ms for a 1024² frame on 8 ranks — more than
-    half of a rank's render time at 8 GPUs; this costs a row scatter of the rank's own share plus a poll.)  All ranks
-    must be on the node that created it: `create` falls back to None when /dev/shm cannot be used, and the caller then
-    keeps `gather_frame`."""
+    half of a rank's render time at 8 GPUs; this costs a row scatter of the rank's own share plus a poll.)
 
-    def __init__(self, path, width, height, world, rank, owner, band_rows=BAND_ROWS):
-        self.path, self.owner, self.world, self.rank = path, owner, world, rank
-        self.frame = np.memmap(path, dtype=np.float32, mode="r+", shape=(height, width, 3))
+    Two buffers, used alternately (frame n lives in buffer n % 2).  `publish(n)` returns only when EVERY rank has
+    published frame n — rank 0 included — and rank 0 publishes frame n + 1 only after it is done with the view of frame n
+    it was given (the view is valid until rank 0's next `publish`).  So when a fast rank writes frame n + 2 into the
+    buffer frame n lived in, rank 0 has already entered publish(n + 1), i.e. let go of frame n: no rank ever writes into
+    a buffer that is being read, and no extra "consumed" word is needed.  The poll backs off (sleep) so that ranks
+    sharing cores do not starve the ones they wait for.  The file is unlinked as soon as every rank has mapped it: a crash
+    leaks nothing.  All ranks must be on the node that created it: `create` returns None when /dev/shm cannot be used
+    and the caller keeps `gather_frame`."""
+
+    def __init__(self, path, width, height, world, rank, band_rows=BAND_ROWS):
+        self.world, self.rank = world, rank
+        fb = self._frame_bytes(width, height)
+        self.frames = [np.memmap(path, dtype=np.float32, mode="r+", offset=k * fb, shape=(height, width, 3)) for k in range(2)]
         # one sequence number per rank behind the pixels: "my rows of frame n are in place"
-        self.seq = np.memmap(path, dtype=np.int64, mode="r+", offset=self._frame_bytes(width, height), shape=(world,))
+        self.seq = np.memmap(path, dtype=np.int64, mode="r+", offset=2 * fb, shape=(world,))
         self.step = 0
         self.rows = owned_rows(height, world, rank, band_rows)
+        self.wait_s = 0.0  # time spent in the poll of the last publish (bench.py reports it)
 
     @staticmethod
     def _frame_bytes(width, height):
-        return (width * height * 3 * 4 + 63) // 64 * 64
+        return (width * height * 3 * 4 + 4095) // 4096 * 4096
 
     @classmethod
     def create(cls, width, height, world, rank, group=None, band_rows=BAND_ROWS):
@@ -92,42 +101,51 @@ class SharedFrame:
             try:
                 path = f"/dev/shm/pbrs_frame_{os.getpid()}"
                 with open(path, "wb") as f:
-                    f.truncate(cls._frame_bytes(width, height) + 8 * world)  # zero-filled: every sequence number starts at 0
+                    f.truncate(2 * cls._frame_bytes(width, height) + 8 * world)  # zero-filled: every sequence number starts at 0
                 name[0] = path
             except OSError:
                 name[0] = None
         dist.broadcast_object_list(name, src=0, group=group)
-        ok = [name[0] is not None and os.path.exists(name[0])]  # a rank on another node does not see the file
+        sf, ok = None, False
+        try:
+            if name[0] is not None and os.path.exists(name[0]):  # a rank on another node does not see the file
+                sf = cls(name[0], width, height, world, rank, band_rows=band_rows)
+                ok = True
+        except (OSError, ValueError):
+            sf = None
         oks = [None] * world
-        dist.all_gather_object(oks, ok[0], group=group)
+        dist.all_gather_object(oks, ok, group=group)  # also: every rank that can map the file has done so by now
+        if rank == 0 and name[0]:
+            try:
+                os.unlink(name[0])  # the mappings keep the memory alive; nothing is left behind if a rank dies
+            except OSError:
+                pass
         if not all(oks):
-            if rank == 0 and name[0]:
-                os.unlink(name[0])
+            if sf is not None:
+                sf.close()
             return None
-        return cls(name[0], width, height, world, rank, owner=(rank == 0), band_rows=band_rows)
+        return sf
 
-    def publish(self, share, group=None, timeout=120.0):
-        """Writes this rank's packed rows into the frame and waits until every rank has done so for this frame.  Returns
-        the frame (a view of the shared buffer) on rank 0, None elsewhere.  The wait is a poll of the ranks' sequence
-        numbers in the same shared mapping (tens of microseconds; a gloo barrier is ≈1 ms at 8 ranks): x86 keeps a
+    def publish(self, share, timeout=120.0):
+        """Writes this rank's packed rows into the current frame and waits until every rank has done so.  Returns that
+        frame on rank 0 (a view of the shared buffer, valid until rank 0's next publish) and None elsewhere.  x86 keeps a
         rank's row stores ahead of its sequence store, and a reader's sequence load ahead of its row loads."""
         import time
-        if len(self.rows):
-            self.frame[self.rows] = share
         self.step += 1
+        frame = self.frames[self.step % 2]
+        if len(self.rows):
+            frame[self.rows] = share
         self.seq[self.rank] = self.step
-        deadline = time.monotonic() + timeout
+        t0 = time.monotonic()
+        deadline, pause = t0 + timeout, 0.0
         while int(self.seq.min()) < self.step:
             if time.monotonic() > deadline:
                 raise RuntimeError(f"rank {self.rank}: frame {self.step} incomplete after {timeout} s (sequence numbers {self.seq.tolist()})")
-        return self.frame if self.rank == 0 else None
+            time.sleep(pause)  # 0 first (yield), then up to 200 us
+            pause = min(200e-6, pause * 2 + 10e-6)
+        self.wait_s = time.monotonic() - t0
+        return frame if self.rank == 0 else None
 
     def close(self):
-        import os
-        del self.frame
-        del self.seq
-        if self.owner:
-            try:
-                os.unlink(self.path)
-            except OSError:
-                pass
+        self.frames = None
+        self.seq = None

@@ -80,3 +80,57 @@ def test_two_rank_gloo_gather_reproduces_the_single_process_frame():
         p.join(60)
         assert p.exitcode == 0
     assert ok, "frame gathered from 2 ranks differs from the single-process frame"
+
+
+def _frames_worker(rank, world, port, q):
+    """Consecutive DIFFERENT frames through SharedFrame with one rank racing ahead: rank 0 holds on to every frame for a
+    while before it checks it, rank 1 publishes the next frames as fast as it can."""
+    import time
+
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h, n_frames = 16, 50, 6
+    shared = tiling.SharedFrame.create(w, h, world, rank)
+    assert shared is not None
+    if rank == 0:  # rank 0 created it and unlinks it once every rank has mapped it
+        assert not os.path.exists(f"/dev/shm/pbrs_frame_{os.getpid()}"), "the frame file must be unlinked once it is mapped"
+    rows = tiling.owned_rows(h, world, rank)
+
+    def content(frame_no):  # every pixel names its frame, row and channel
+        full = np.empty((h, w, 3), dtype=np.float32)
+        full[:] = (frame_no * 1000.0 + np.arange(h, dtype=np.float32))[:, None, None] + np.arange(3, dtype=np.float32) / 4
+        return full
+
+    ok = True
+    for n in range(1, n_frames + 1):
+        view = shared.publish(content(n)[rows])
+        if rank == 0:
+            time.sleep(0.05)  # rank 1 is already publishing frame n + 1 (and must not get further than that)
+            ok = ok and bool((np.asarray(view) == content(n)).all())
+        else:
+            assert view is None
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    shared.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_shared_frame_keeps_consecutive_frames_apart():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frames_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok, "a frame read by rank 0 held rows of a later frame"

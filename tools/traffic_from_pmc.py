@@ -1,8 +1,20 @@
-"""Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate passes, TCC slots) into per-launch HBM
-traffic per kernel, with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE
-are in KiB; FETCH_SIZE reports half of the bytes of a coalesced stream (calibrated here on k_accumulate, whose byte
-count is known: it reads 12 B per path slot + 12 B per pixel and writes 12 B per pixel)."""
-import json, re, sys
+"""Turns rocprofv3 TCC counter passes (tools/pmc_summary.py outputs) into HBM traffic per launch per kernel.
+
+    python tools/traffic_from_pmc.py GEOMETRY.json fetch.txt write.txt [rdreq_sizes.txt [wrreq.txt]]
+
+Units and gfx950 corrections as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are in
+KiB and come from the L2's memory-side request counters (Infinity-Cache hits are counted, not excluded); on gfx950
+FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact.  The
+doubling is calibrated on k_accumulate (a pure coalesced stream of known size) and recorded.  Because the guide calls
+other access widths uncalibrated, the optional third pass gives an independent figure for every kernel from the
+request-size counters of gfx950 (TCC_EA0_RDREQ_{32B,64B,128B}): read bytes = 32 n32 + 64 n64 + 128 n128, with requests
+of no recorded size counted at 64 B — reported as hbm_read_by_request_size next to hbm_read; bench.py uses the larger of
+the two so that a roofline fraction is never flattered.
+"""
+import json
+import re
+import sys
+
 
 def parse(path):
     out, cur = {}, None
@@ -16,17 +28,38 @@ def parse(path):
             out[cur][k] = float(v)
     return out
 
-fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
-n_slots, n_pixels = int(sys.argv[3]), int(sys.argv[4])
-acc = fetch["k_accumulate"]
-known_read = 12.0 * n_slots + 12.0 * n_pixels
-read_scale = known_read / (acc["FETCH_SIZE"] * 1024 / acc["dispatches"])
-res = {"unit": "bytes per launch", "fetch_size_scale_calibrated_on_k_accumulate": read_scale, "kernels": {}}
+
+geo = json.load(open(sys.argv[1]))
+fetch, write = parse(sys.argv[2]), parse(sys.argv[3])
+sizes = parse(sys.argv[4]) if len(sys.argv) > 4 else {}
+wr = parse(sys.argv[5]) if len(sys.argv) > 5 else {}
+n_pixels = geo["pixels"]
+n_slots = n_pixels * geo["samples_per_pass"]
+res = {"unit": "bytes per launch", "geometry": geo, "kernels": {}}
+acc = fetch.get("k_accumulate")
+if acc:
+    known_read = float(geo.get("accumulate_read_bytes_per_slot", 12)) * n_slots + 12.0 * n_pixels
+    res["fetch_size_scale_calibrated_on_k_accumulate"] = known_read / (acc["FETCH_SIZE"] * 1024 / acc["dispatches"])
 for k in fetch:
     if k.startswith("__") or k not in write:
         continue
     d = fetch[k]["dispatches"]
     rd = fetch[k]["FETCH_SIZE"] * 1024 / d * 2.0   # guide: FETCH_SIZE = half the streamed bytes on gfx950
-    wr = write[k]["WRITE_SIZE"] * 1024 / d
-    res["kernels"][k] = {"launches": d, "hbm_read": rd, "hbm_write": wr, "hbm_total": rd + wr}
+    wb = write[k]["WRITE_SIZE"] * 1024 / d
+    row = {"launches": d, "hbm_read": rd, "hbm_write": wb}
+    if k in sizes:
+        s, ds = sizes[k], sizes[k]["dispatches"]
+        n32, n64, n128 = s.get("TCC_EA0_RDREQ_32B_sum", 0.0), s.get("TCC_EA0_RDREQ_64B_sum", 0.0), s.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+        rest = max(s.get("TCC_EA0_RDREQ_sum", 0.0) - n32 - n64 - n128, 0.0)
+        row["hbm_read_by_request_size"] = (32 * n32 + 64 * (n64 + rest) + 128 * n128) / ds
+        row["read_requests"] = {"32B": n32 / ds, "64B": n64 / ds, "128B": n128 / ds, "unsized": rest / ds}
+        rd = max(rd, row["hbm_read_by_request_size"])
+    if k in wr:
+        s, ds = wr[k], wr[k]["dispatches"]
+        row["write_requests"] = {"all": s.get("TCC_EA0_WRREQ_sum", 0.0) / ds, "64B": s.get("TCC_EA0_WRREQ_64B_sum", 0.0) / ds}
+        hit, miss = s.get("TCC_HIT_sum"), s.get("TCC_MISS_sum")
+        if hit is not None and miss is not None and hit + miss > 0:
+            row["l2_hit_rate"] = hit / (hit + miss)
+    row["hbm_total"] = rd + wb
+    res["kernels"][k] = row
 print(json.dumps(res, indent=1))
