@@ -538,6 +538,61 @@ void lambertian_test() {
     CHECK(norm_squared(d) < 1e-5f, "f*cos/pdf = (%.6f %.6f %.6f)", c1.r, c1.g, c1.b);
 }
 
+
+// src/bsdf.rs:159-226 (`mf_refl_test`): BSDF::new_frame reproduces the frame the hit was built with, world_to_local
+// inverts `frame * wo_local`, and a Beckmann (roughness 0.2, Fresnel::Nop) reflection lobe sampled on a 10 x 10 grid
+// returns densities (never a probability mass) whose responses f |wi . n| / pdf are not NaN.
+void mf_refl_test() {
+    const float alpha = roughness_to_alpha(0.2f);
+    MicrofacetDistrib distrib{MicrofacetDistrib::Beckmann, alpha, alpha};
+    std::vector<BXDF> bxdfs{bxdf_microfacet(rgb(1.0f, 1.0f, 1.0f), distrib, fresnel_nop())};
+    Vec3 normal = hat(Vec3{-0.6f, 0.5f, 0.2f});
+    Vec3 dpdu, dpdv;
+    make_coord_system(normal, &dpdu, &dpdv);
+    Mat3 frame = mat3_cols(dpdu, dpdv, normal);
+    auto frob_diff = [](const Mat3& a, const Mat3& b) {  // (a - b).frobenius_norm_squared(), hcm.rs:431-433
+        float sum = 0.0f;
+        for (int i = 0; i < 3; ++i) sum += norm_squared(a.cols[i] - b.cols[i]);
+        return sum;
+    };
+    {  // frame * frame^T - I
+        Mat3 t = mat3_cols(Vec3{frame.cols[0][0], frame.cols[1][0], frame.cols[2][0]}, Vec3{frame.cols[0][1], frame.cols[1][1], frame.cols[2][1]},
+                           Vec3{frame.cols[0][2], frame.cols[1][2], frame.cols[2][2]});
+        Mat3 prod = mat3_cols(frame * t.cols[0], frame * t.cols[1], frame * t.cols[2]);  // hcm.rs:436-446
+        Mat3 eye = mat3_cols(Vec3{1, 0, 0}, Vec3{0, 1, 0}, Vec3{0, 0, 1});
+        CHECK(frob_diff(prod, eye) < 1e-6f, "frame is not orthonormal: %g", frob_diff(prod, eye));
+    }
+    Interaction isect = with_dpdu(isect_rayless(Vec3{3.0f, 2.5f, 2.0f}, 0.2f, 0.8f, normal), dpdu);
+    BSDF bsdf = bsdf_new_frame(isect);
+    bsdf.bxdfs = &bxdfs;
+    CHECK(frob_diff(frame, bsdf.frame) < 1e-6f, "BSDF frame differs from the hit's frame: %g", frob_diff(frame, bsdf.frame));
+    Vec3 wo_local = hat(Vec3{0.6f, 0.0f, 0.8f});
+    Vec3 wo_world = frame * wo_local;
+    CHECK(pn_abs(dot(wo_world, normal) - wo_local[2]) < 1e-3f, "wo_world . n = %g", dot(wo_world, normal));
+    {
+        Omega actual = bsdf.world_to_local(wo_world);
+        CHECK(norm_squared(wo_local - actual) < 1e-6f, "world_to_local(frame * wo) is off by %g", norm_squared(wo_local - actual));
+    }
+    auto uvec = linspace(0.0f, 1.0f, 10, nullptr);
+    int responses = 0;
+    for (float u : uvec)
+        for (float v : uvec) {
+            Color f;
+            Vec3 wi;
+            Prob pr{};
+            bsdf.sample(wo_world, u, v, &f, &wi, &pr);
+            CHECK(!pr.is_mass, "a microfacet reflection returned a probability mass at (%g, %g)", u, v);
+            if (pr.is_mass) continue;
+            const float pdf = pr.density();
+            Color response = f * pn_abs(dot(wi, isect.normal)) * pn_weak_recip(pdf);
+            if (pdf > 0.0f) {
+                CHECK(!pn_isnan(response.r), "NaN response at (%g, %g)", u, v);
+                ++responses;
+            }
+        }
+    CHECK(responses > 0, "no sample of the grid had a positive density");
+}
+
 struct Entry {
     const char* name;
     void (*fn)();
@@ -561,6 +616,7 @@ const Entry kTests[] = {
     {"sphere_sample_pdf_integrate", sphere_sample_pdf_integrate},
     {"observe_sphere_sample_towards", observe_sphere_sample_towards},
     {"lambertian_test", lambertian_test},
+    {"mf_refl_test", mf_refl_test},
 };
 const uint32_t kNumTests = sizeof(kTests) / sizeof(kTests[0]);
 

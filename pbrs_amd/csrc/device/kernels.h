@@ -6,40 +6,38 @@
 //   shadow      tlas/src/bvh.rs:105-113 (any hit) + the radiance add of pathintegrator.rs:35
 //   accumulate  src/main.rs:205-208 (in-order f32 sum over samples, then * 1/spp)
 //
-// One lane owns one path for the whole pass; path state is SoA in HBM at a fixed slot
-// (slot = k * P + pixel: lanes of a wave are neighbouring pixels of one sample index, so every
-// column access is a coalesced 256-byte row per wave).  Stages communicate through u32 slot queues;
-// the `break`s of the bounce loop (pathintegrator.rs:25-27, :48-50, :67-69) become "not appended to
-// the next queue", compacted with __ballot + mbcnt prefixes summed per block in LDS (two atomics per block).
-// Shadow rays travel as 64-byte records written at their queue position (PathState::shadow_rays).
+// One lane owns one path vertex (k_shade) or one ray (k_extend / k_shadow).  What a path carries from bounce to bounce
+// travels as DENSE records at the path's position in the bounce's queue — k_shade writes the next ray where the
+// compaction puts the path, k_extend writes the hit next to it, k_shade reads both back — so every access of the
+// traversal kernels and all but one of k_shade's is a full-width coalesced 16-byte-per-lane stream.  Only the radiance
+// accumulator stays at a fixed address per path (slot = k * P + pixel: k_accumulate sums the samples of a pixel in
+// order).  The `break`s of the bounce loop (pathintegrator.rs:25-27, :48-50, :67-69) become "not appended to the next
+// queue", compacted with __ballot + mbcnt prefixes summed per block in LDS (two atomics per block).
 #pragma once
 #include "lights.h"
 #include "textures.h"
 #include "traverse.h"
 
 struct PathState {
-    float *ox, *oy, *oz, *dx, *dy, *dz;  // current ray (t_max is always +inf for path rays: Ray::new)
-    float *br, *bg, *bb;                 // beta
-    float *lr, *lg, *lb;                 // radiance
-    uint64_t* rng;
-    uint32_t* flags;  // bit 0: specular_bounce
-    float* ht;        // hit record
-    uint32_t *hinst, *hprim;
-    float *hb1, *hb2;
-    // Next-event estimation hand-off.  Every shadow ray is one 64-byte record (four 16-byte vectors, written and read
-    // with full-width coalesced accesses at its queue position):
-    //   [0] origin.xyz, t_max          [1] dir.xyz, slot | ray index << 31 | lone << 30
-    //   [2] lone ray: what the path's radiance gains if the ray is unoccluded      [3] ... if it is occluded
-    // A path that casts both of its rays (the two MIS terms of an area light) cannot be finished by either tracing
-    // lane: its terms wait in the columns below and k_nee_resolve combines them with the two occlusion bytes.
-    float4* shadow_rays;
-    float* sc[2][3];
-    float* nb[3];     // beta at the time of the estimate
-    float* nscale;    // 1 / light_pdf
-    float* npost;     // factor applied after beta * estimate (1 for the path integrator; the direct integrator's 1 / mass)
-    uint8_t* occ[2];  // written by k_shadow: 1 = the ray is occluded
+    // Path records by queue position i, structure-of-float4-arrays, ping-pong by bounce parity (k_shade reads set b & 1
+    // and writes set (b + 1) & 1):
+    //   q[.][0][i] = origin.xyz, slot | specular_bounce << 31        (t_max is always +inf for path rays: Ray::new)
+    //   q[.][1][i] = dir.xyz,    RNG state, low word
+    //   q[.][2][i] = beta.xyz,   RNG state, high word
+    float4* q[2][3];
+    float4* hit;  // [i] = t, inst (0xffffffff: miss), prim, -   written by k_extend at the ray's queue position
+    float4* L;    // [slot] = radiance.xyz, w: the direct integrator's 1 / mass (src/directlighting.rs:37), else unused
+    // Next-event estimation hand-off.  Shadow rays by position j in the bounce's shadow queue:
+    //   sr[0][j] = origin.xyz, t_max        sr[1][j] = dir.xyz, item
+    //   sr[2][j] = lone ray: the path's radiance if the ray is unoccluded (k_shade has stored the occluded outcome in L)
+    // item = slot | 1 << 30 for a path's only shadow ray (the lane that traces it finishes the estimate), else
+    // slot | ray index << 31: a path that casts both of its rays (the two MIS terms of an area light) cannot be finished
+    // by either tracing lane — its terms wait in nee[] (by slot) and k_nee_resolve combines them with the two occlusion bytes.
+    float4* sr[3];
+    float4* nee[3];   // [slot]: c1.xyz, 1 / light_pdf | c2.xyz, post factor | beta at the time of the estimate, -
+    uint8_t* occ[2];  // [slot], written by k_shadow: 1 = the ray is occluded
 };
-#define PBRS_STATE_WORDS 33
+#define PBRS_STATE_BYTES_PER_PATH (2u * 48u + 16u + 16u + 2u * 48u + 48u + 2u + 4u)  // records above + the nee queue entry
 
 struct RenderConst {
     pbrs_camera cam;
@@ -54,22 +52,16 @@ struct RenderConst {
     uint64_t seed;
 };
 
-// Column access by path slot.  Slots stay below 2^30 (check_params), so the byte offset fits 32 bits: written as
-// base + zext(slot << 2) the access compiles to the scalar-base form (global_load_dword v, v_off, s[base:base+1]) with
-// ONE shared offset register per slot instead of a 64-bit address computed per column.
+// Byte / word columns by path slot (the nee hand-off's occlusion bytes).  Slots stay below 2^28 (check_params).
 template <class T>
 PD T& at(T* base, uint32_t slot) {
-    static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 1, "column element size");
+    static_assert(sizeof(T) == 4 || sizeof(T) == 1, "column element size");
     return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)(uint32_t)(slot * (uint32_t)sizeof(T)));
 }
-PD f3 ld_col(const float* a, const float* b, const float* c, uint32_t i) {
-    return mk3(at(const_cast<float*>(a), i), at(const_cast<float*>(b), i), at(const_cast<float*>(c), i));
-}
-PD void st_col(float* a, float* b, float* c, uint32_t i, f3 v) {
-    at(a, i) = v.x;
-    at(b, i) = v.y;
-    at(c, i) = v.z;
-}
+PD float4 pack4(f3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
+PD float4 pack4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+PD f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+#define PBRS_SLOT_MASK 0x3fffffffu
 
 // ---- raygen --------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
@@ -89,12 +81,11 @@ __global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
     float x = (float)col + pn_fract(jx);
     float y = (float)row + pn_fract(jy);
     f3 dir = ld3(rc.cam.c) + ld3(rc.cam.a) * x + ld3(rc.cam.b) * y;
-    st_col(st.ox, st.oy, st.oz, slot, ld3(rc.cam.center));
-    st_col(st.dx, st.dy, st.dz, slot, dir);
-    st_col(st.br, st.bg, st.bb, slot, gray(1.0f));
-    st_col(st.lr, st.lg, st.lb, slot, gray(0.0f));
-    at(st.rng, slot) = rng;
-    at(st.flags, slot) = 0u;
+    // bounce 0: the queue position of a path is its slot
+    st.q[0][0][slot] = pack4(ld3(rc.cam.center), slot);
+    st.q[0][1][slot] = pack4(dir, (uint32_t)rng);
+    st.q[0][2][slot] = pack4(gray(1.0f), (uint32_t)(rng >> 32));
+    st.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 struct GlobalCounters {  // instrumented variant only
@@ -272,17 +263,19 @@ PD uint32_t wave_fetch(WaveWork& w, bool need, uint32_t* heads, uint32_t n) {
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
 // handed a new ray at the next refill, the walks of the other lanes continue where they were.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES) k_extend(DevScene S, PathState st, const uint32_t* queue, const uint32_t* count, uint32_t n_direct,
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES) k_extend(DevScene S, PathState st, uint32_t set, const uint32_t* count, uint32_t n_direct,
                                                uint32_t* next, GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
-    const uint32_t n = queue ? *count : n_direct;
+    const uint32_t n = count ? *count : n_direct;
+    const float4* __restrict__ q0 = st.q[set][0];
+    const float4* __restrict__ q1 = st.q[set][1];
     LaneStack stk{lds_stack + threadIdx.x, S.world + (blockIdx.x * PBRS_TRAVERSAL_BLOCK + threadIdx.x) * 3u};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
     ClosestWalk<STATS, FEAT> walk;
     walk.mode = PBRS_WALK_IDLE;
-    uint32_t slot = 0;
+    uint32_t item = 0;  // queue position of the lane's ray
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
@@ -290,19 +283,17 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
             if (walk.mode == PBRS_WALK_DONE) {  // finished walks are retired in batches, at refill time
                 const Hit& h = walk.best;
                 nhit += h.inst != 0xffffffffu ? 1u : 0u;
-                at(st.ht, slot) = h.t;
-                at(st.hinst, slot) = h.inst;
-                at(st.hprim, slot) = h.prim;
-                at(st.hb1, slot) = h.b1;
-                at(st.hb2, slot) = h.b2;
+                // k_shade rebuilds the Interaction from (t, inst, prim): the barycentrics are recomputed there, as the
+                // reference's intersect does for the winning primitive
+                st.hit[item] = make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), 0.0f);
                 walk.mode = PBRS_WALK_IDLE;
             }
             if (work.left()) {
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
-                    slot = queue ? queue[idx] : idx;
-                    f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
-                    walk.start(S, o, d, pn_inf(), stk);
+                    item = idx;
+                    const float4 a = q0[idx], b = q1[idx];
+                    walk.start(S, xyz(a), xyz(b), pn_inf(), stk);
                     nrays++;
                 }
                 walk.scan_wave(S, cnt);
@@ -338,9 +329,8 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 
 // ---- shade -----------------------------------------------------------------------------------------------------
 template <uint32_t INTEG, bool TEX>
-__global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* queue,
-                                              const uint32_t* count, uint32_t n_direct, uint32_t* queue_out, uint32_t* count_out,
-                                              uint32_t* nee_queue, unsigned long long* nee_shadow_count) {
+__global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
+                                              uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count) {
     // per-hit lobe lists of textured materials (Bsdf::hit_lobe / hit_albedo); absent from the untextured instantiation
     __shared__ uint32_t s_hit_lobe[TEX ? PBRS_MAX_BXDFS * 256 : 1];
     __shared__ float s_hit_albedo[TEX ? 3 * PBRS_MAX_BXDFS * 256 : 1];
@@ -349,26 +339,34 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
     unsigned long long probe_t = __builtin_amdgcn_s_memtime();
 #endif
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n = queue ? *count : n_direct;
+    uint32_t n = count ? *count : n_direct;
     bool valid = i < n;
     bool alive = false, cast0 = false, cast1 = false;
     uint32_t slot = 0;
     ShadowRay sr0, sr1;  // the rays to cast, kept until their queue positions are known
     sr0.o = sr0.d = sr1.o = sr1.d = gray(0.0f);
     sr0.t_max = sr1.t_max = -1.0f;
-    f3 add_v = gray(0.0f), add_o = gray(0.0f);
+    f3 L_vis = gray(0.0f);  // a lone shadow ray: the path's radiance if it turns out unoccluded
+    // the path's next record, kept until the compaction below has given it a queue position
+    f3 next_o = gray(0.0f), next_d = gray(0.0f), next_beta = gray(0.0f);
+    uint64_t next_rng = 0;
+    uint32_t next_spec = 0;
     if (valid) {
-        slot = queue ? queue[i] : i;
-        f3 o = ld_col(st.ox, st.oy, st.oz, slot), d = ld_col(st.dx, st.dy, st.dz, slot);
-        f3 beta = ld_col(st.br, st.bg, st.bb, slot);
-        f3 L = ld_col(st.lr, st.lg, st.lb, slot);
-        uint32_t flags = at(st.flags, slot);
+        const uint32_t set = bounce & 1u;
+        const float4 r0 = st.q[set][0][i], r1 = st.q[set][1][i], r2 = st.q[set][2][i], rh = st.hit[i];
+        slot = __float_as_uint(r0.w) & PBRS_SLOT_MASK;
+        const float4 rl = st.L[slot];
+        f3 o = xyz(r0), d = xyz(r1);
+        f3 beta = xyz(r2);
+        f3 L = xyz(rl);
+        float post_w = rl.w;  // the direct integrator's 1 / mass rides next to the radiance
+        const uint64_t rng_in = ((uint64_t)__float_as_uint(r2.w) << 32) | (uint64_t)__float_as_uint(r1.w);
         Hit h;
-        h.t = at(st.ht, slot);
-        h.inst = at(st.hinst, slot);
-        h.prim = at(st.hprim, slot);
+        h.t = rh.x;
+        h.inst = __float_as_uint(rh.y);
+        h.prim = __float_as_uint(rh.z);
         bool has_hit = h.inst != 0xffffffffu;
-        bool specular_bounce = (flags & 1u) != 0;
+        bool specular_bounce = (__float_as_uint(r0.w) >> 31) != 0;
         const pbrs_material* mat = nullptr;
         if (has_hit) mat = S.mats + S.inst[h.inst].material;
         // The direct-lighting integrator (INTEG 1, src/directlighting.rs:14-56) runs on the same stage: bounce 0 is
@@ -434,7 +432,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                             reflect_pr = r0 + (1.0f - r0) * pn_powi(1.0f - cosine, 5);
                             albedo = ld3(vis.albedo);  // self.transmit
                         }
-                        uint64_t rng = at(st.rng, slot);
+                        uint64_t rng = rng_in;
                         if (pn_rng_f32(&rng) < reflect_pr) albedo = ld3(lobe0.albedo);
                         break;
                     }
@@ -456,12 +454,12 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                 emitter_hit = true;
             }
         } else {
-            post = __uint_as_float(flags);
+            post = post_w;
             if (!has_hit) L = L + cmul(env_eval(S, d), beta) * post;  // :54, then spec_refl * f * pr.mass().weak_recip() (:37)
         }
         PBRS_SHADE_MARK(0);  // queue + state loads, emission
         if (has_hit && !emitter_hit) {
-            uint64_t rng = at(st.rng, slot);
+            uint64_t rng = rng_in;
 #ifdef PBRS_ABL_NO_RECON  // timing-only ablation build: skips the Interaction rebuild, results are wrong
             Isect is;
             is.pos = o + h.t * d;
@@ -581,13 +579,9 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                 cast1 = v2.t_max >= 0.0f;
                 if (cast0 && cast1) {
                     // two rays (area light, both MIS terms alive): directlighting.rs:193 and :219 add up in k_nee_resolve
-                    for (int r = 0; r < 3; ++r) {
-                        at(st.sc[0][r], slot) = comp(c1, r);
-                        at(st.sc[1][r], slot) = comp(c2, r);
-                        at(st.nb[r], slot) = comp(beta, r);
-                    }
-                    at(st.nscale, slot) = scale;
-                    at(st.npost, slot) = post;
+                    st.nee[0][slot] = pack4(c1, scale);
+                    st.nee[1][slot] = pack4(c2, post);
+                    st.nee[2][slot] = pack4(beta, 0.0f);
                 } else if (cast0 || cast1) {
                     // one ray: the lane that traces it finishes the estimate (directlighting.rs:193 / :219 / :90-96, then
                     // :98 and pathintegrator.rs:35), so both outcomes are evaluated here with the reference's operations
@@ -603,12 +597,16 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                         one_o = c2;
                         one_v = cr;
                     }
-                    add_v = cmul(beta, one_v * scale);
-                    add_o = cmul(beta, one_o * scale);
+                    f3 add_v = cmul(beta, one_v * scale);
+                    f3 add_o = cmul(beta, one_o * scale);
                     if (INTEG != PBRS_INTEGRATOR_PATH) {
                         add_v = add_v * post;
                         add_o = add_o * post;
                     }
+                    // pathintegrator.rs:35 is one f32 add per channel either way: the occluded outcome goes into L here,
+                    // the unoccluded one travels with the ray and replaces it (k_shadow) — nothing below touches L
+                    L_vis = L + add_v;
+                    L = L + add_o;
                 } else {
                     // nothing to test: the estimate is black; pathintegrator.rs:35 still adds beta * (black * n)
                     f3 z = cmul(beta, gray(0.0f) * scale);
@@ -627,11 +625,11 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                     f3 no, nd;
                     spawn_ray(is, wi, no, nd);
                     alive = true;
-                    st_col(st.ox, st.oy, st.oz, slot, no);
-                    st_col(st.dx, st.dy, st.dz, slot, nd);
-                    st_col(st.br, st.bg, st.bb, slot, f);
-                    at(st.rng, slot) = rng;
-                    at(st.flags, slot) = __float_as_uint(pn_weak_recip(pr.v));
+                    next_o = no;
+                    next_d = nd;
+                    next_beta = f;
+                    next_rng = rng;
+                    post_w = pn_weak_recip(pr.v);
                 }
             } else {
             PBRS_SHADE_MARK(5);  // NEE bookkeeping (cast flags, both outcomes)
@@ -655,16 +653,16 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                 }
                 if (cont && bounce + 1 < rc.max_depth) {
                     alive = true;
-                    st_col(st.ox, st.oy, st.oz, slot, no);
-                    st_col(st.dx, st.dy, st.dz, slot, nd);
-                    st_col(st.br, st.bg, st.bb, slot, beta);
-                    at(st.rng, slot) = rng;
-                    at(st.flags, slot) = specular_bounce ? 1u : 0u;
+                    next_o = no;
+                    next_d = nd;
+                    next_beta = beta;
+                    next_rng = rng;
+                    next_spec = specular_bounce ? 0x80000000u : 0u;
                 }
             }
             }
         }
-        st_col(st.lr, st.lg, st.lb, slot, L);
+        st.L[slot] = pack4(L, post_w);
         PBRS_SHADE_MARK(6);  // bounce: BSDF sample, beta, spawn, roulette, state stores
     }
     // Stream compaction of the three outputs.  A hot queue tail serialises at ~10 ns per atomic on gfx950, so the
@@ -707,25 +705,24 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
         b_nee += s_cnt[w][1];
         b_sh += s_cnt[w][2] + s_cnt[w][3];
     }
-    if (alive) queue_out[b_alive + lane_prefix(m_alive)] = slot;
+    if (alive) {
+        const uint32_t j = b_alive + lane_prefix(m_alive), out = (bounce + 1u) & 1u;
+        st.q[out][0][j] = pack4(next_o, slot | next_spec);
+        st.q[out][1][j] = pack4(next_d, (uint32_t)next_rng);
+        st.q[out][2][j] = pack4(next_beta, (uint32_t)(next_rng >> 32));
+    }
     if (both) nee_queue[b_nee + lane_prefix(m_nee)] = slot;
     if (cast0) {
-        float4* rec = st.shadow_rays + 4ull * (b_sh + lane_prefix(m_c0));
-        rec[0] = make_float4(sr0.o.x, sr0.o.y, sr0.o.z, sr0.t_max);
-        rec[1] = make_float4(sr0.d.x, sr0.d.y, sr0.d.z, __uint_as_float(slot | lone));
-        if (lone) {
-            rec[2] = make_float4(add_v.x, add_v.y, add_v.z, 0.0f);
-            rec[3] = make_float4(add_o.x, add_o.y, add_o.z, 0.0f);
-        }
+        const size_t j = (size_t)b_sh + lane_prefix(m_c0);
+        st.sr[0][j] = pack4(sr0.o, sr0.t_max);
+        st.sr[1][j] = pack4(sr0.d, slot | lone);
+        if (lone) st.sr[2][j] = pack4(L_vis, 0.0f);
     }
     if (cast1) {
-        float4* rec = st.shadow_rays + 4ull * (b_sh + s_cnt[wave][2] + lane_prefix(m_c1));
-        rec[0] = make_float4(sr1.o.x, sr1.o.y, sr1.o.z, sr1.t_max);
-        rec[1] = make_float4(sr1.d.x, sr1.d.y, sr1.d.z, __uint_as_float(slot | 0x80000000u | lone));
-        if (lone) {
-            rec[2] = make_float4(add_v.x, add_v.y, add_v.z, 0.0f);
-            rec[3] = make_float4(add_o.x, add_o.y, add_o.z, 0.0f);
-        }
+        const size_t j = (size_t)b_sh + s_cnt[wave][2] + lane_prefix(m_c1);
+        st.sr[0][j] = pack4(sr1.o, sr1.t_max);
+        st.sr[1][j] = pack4(sr1.d, slot | 0x80000000u | lone);
+        if (lone) st.sr[2][j] = pack4(L_vis, 0.0f);
     }
 #ifdef PBRS_PROBE_SHADE
     PBRS_SHADE_MARK(7);  // compaction + queue / record writes
@@ -754,13 +751,16 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
         if ((uint32_t)__popcll(live) < S.refill_below) {
             if (walk.mode == PBRS_WALK_DONE) {
                 const bool occluded = walk.occluded;
-                const uint32_t slot = item & 0x3fffffffu, r = item >> 31;
+                const uint32_t slot = item & PBRS_SLOT_MASK, r = item >> 31;
                 if (item & 0x40000000u) {
-                    // the path's only shadow ray: k_shade left both outcomes in the record
-                    const float4 add = st.shadow_rays[4ull * rec + (occluded ? 3u : 2u)];
-                    f3 L = ld_col(st.lr, st.lg, st.lb, slot);
-                    L = L + mk3(add.x, add.y, add.z);
-                    st_col(st.lr, st.lg, st.lb, slot, L);
+                    // the path's only shadow ray: k_shade stored the occluded outcome in L and sent the other one along
+                    if (!occluded) {
+                        const float4 lv = st.sr[2][rec];
+                        float* l = reinterpret_cast<float*>(st.L + slot);  // .w (the direct integrator's 1 / mass) stays
+                        l[0] = lv.x;
+                        l[1] = lv.y;
+                        l[2] = lv.z;
+                    }
                 } else {
                     at(st.occ[r], slot) = occluded ? 1 : 0;
                 }
@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
                     rec = idx;
-                    const float4 q0 = st.shadow_rays[4ull * idx], q1 = st.shadow_rays[4ull * idx + 1];
+                    const float4 q0 = st.sr[0][idx], q1 = st.sr[1][idx];
                     item = __float_as_uint(q1.w);
                     walk.start(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, stk);
                     nrays++;
@@ -794,15 +794,16 @@ __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_
     uint32_t slot = queue[i];
     // only area-light estimates cast two rays: Ld = term 1 (light sample, :193) + term 2 (BSDF sample, :219)
     bool occ0 = at(st.occ[0], slot) != 0, occ1 = at(st.occ[1], slot) != 0;
-    f3 c1 = mk3(at(st.sc[0][0], slot), at(st.sc[0][1], slot), at(st.sc[0][2], slot));
-    f3 c2 = mk3(at(st.sc[1][0], slot), at(st.sc[1][1], slot), at(st.sc[1][2], slot));
+    const float4 n0 = st.nee[0][slot], n1 = st.nee[1][slot], n2 = st.nee[2][slot];
+    f3 c1 = xyz(n0), c2 = xyz(n1);
     f3 one = gray(0.0f);
     if (!occ0) one = one + c1;
     if (!occ1) one = one + c2;
-    f3 nb = mk3(at(st.nb[0], slot), at(st.nb[1], slot), at(st.nb[2], slot));
-    f3 L = ld_col(st.lr, st.lg, st.lb, slot);
-    L = L + cmul(nb, one * at(st.nscale, slot)) * at(st.npost, slot);  // npost is 1 for the path integrator: x * 1 == x bit for bit
-    st_col(st.lr, st.lg, st.lb, slot, L);
+    f3 nb = xyz(n2);
+    const float4 rl = st.L[slot];
+    f3 L = xyz(rl);
+    L = L + cmul(nb, one * n0.w) * n1.w;  // the post factor is 1 for the path integrator: x * 1 == x bit for bit
+    st.L[slot] = pack4(L, rl.w);
 }
 
 // ---- accumulate / finalize -----------------------------------------------------------------------------------------
@@ -813,7 +814,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PathState st, float* sum, ui
     f3 s = mk3(sum[p], sum[n_pixels + p], sum[2 * n_pixels + p]);
     for (uint32_t k = 0; k < k_count; ++k) {
         uint32_t slot = k * n_pixels + p;
-        s = s + ld_col(st.lr, st.lg, st.lb, slot);
+        s = s + xyz(st.L[slot]);
     }
     sum[p] = s.x;
     sum[n_pixels + p] = s.y;
@@ -894,11 +895,13 @@ __global__ void __launch_bounds__(256) k_numeric_eval(uint32_t fn, uint32_t n, c
 __global__ void __launch_bounds__(256) k_export_rays(PathState st, uint32_t n, float* origins, float* dirs) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    origins[3 * i] = st.ox[i]; origins[3 * i + 1] = st.oy[i]; origins[3 * i + 2] = st.oz[i];
-    dirs[3 * i] = st.dx[i]; dirs[3 * i + 1] = st.dy[i]; dirs[3 * i + 2] = st.dz[i];
+    const float4 o = st.q[0][0][i], d = st.q[0][1][i];  // as k_raygen leaves them: queue position = slot
+    origins[3 * i] = o.x; origins[3 * i + 1] = o.y; origins[3 * i + 2] = o.z;
+    dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
 }
 __global__ void __launch_bounds__(256) k_export_radiance(PathState st, uint32_t n, float* rgb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    rgb[3 * i] = st.lr[i]; rgb[3 * i + 1] = st.lg[i]; rgb[3 * i + 2] = st.lb[i];
+    const float4 l = st.L[i];
+    rgb[3 * i] = l.x; rgb[3 * i + 1] = l.y; rgb[3 * i + 2] = l.z;
 }

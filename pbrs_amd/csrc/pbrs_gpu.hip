@@ -46,10 +46,9 @@ struct pbrs_ctx {
 
     // working set
     size_t cap_slots = 0, cap_pixels = 0;
-    void* state_mem = nullptr;
+    void* state_mem = nullptr;    // every per-path array of PathState, carved out of one allocation
     PathState st{};
-    uint32_t* queues = nullptr;   // 3 * cap_slots: ping, pong, nee
-    float4* shadow_rays = nullptr; // 2 * cap_slots records of 64 bytes (PathState::shadow_rays)
+    uint32_t* neeq = nullptr;     // cap_slots: slots of the paths whose estimate waits for two shadow rays
     uint4* world = nullptr;       // PBRS_TRAVERSAL_LANES x 48 bytes: parked world rays of the traversal lanes
     uint32_t* counters = nullptr; // kCounterWords: act, ns (u64), extend work heads, shadow work heads
     float* sum = nullptr;         // 3 * cap_pixels, planar
@@ -102,57 +101,55 @@ void free_scene(pbrs_ctx* c) {
 }
 
 void free_work(pbrs_ctx* c) {
+    // capacities first: whatever happens below, no later call may take the old pointers for valid
+    c->cap_slots = c->cap_pixels = 0;
+    c->st = PathState{};
     if (c->state_mem) (void)hipFree(c->state_mem);
-    if (c->queues) (void)hipFree(c->queues);
-    if (c->shadow_rays) (void)hipFree(c->shadow_rays);
     if (c->sum) (void)hipFree(c->sum);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
     c->state_mem = nullptr;
-    c->queues = nullptr;
-    c->shadow_rays = nullptr;
+    c->neeq = nullptr;
     c->sum = nullptr;
     c->rgb_dev = nullptr;
-    c->cap_slots = c->cap_pixels = 0;
 }
 
-// Carves the SoA columns out of one allocation; every column starts 256-byte aligned.
+// Carves the per-path arrays of PathState out of one allocation; every array starts 256-byte aligned.  The new
+// capacities are published only after every allocation has succeeded: a failure leaves the context without a working
+// set (cap_* = 0, PathState cleared), never with pointers into freed memory.
 int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
     if (n_slots > c->cap_slots) {
+        c->cap_slots = 0;
+        c->st = PathState{};
+        c->neeq = nullptr;
         if (c->state_mem) (void)hipFree(c->state_mem);
-        if (c->queues) (void)hipFree(c->queues);
-        if (c->shadow_rays) (void)hipFree(c->shadow_rays);
         c->state_mem = nullptr;
-        c->queues = nullptr;
-        c->shadow_rays = nullptr;
-        size_t col = ((n_slots * 4 + 255) / 256) * 256;
-        const size_t n_cols = 6 + 3 + 3 + 2 /*rng*/ + 1 + 5 + 6 + 3 + 2 + 1 /*occ bytes*/;
-        HIPCHK(c, hipMalloc(&c->state_mem, col * n_cols));
-        char* base = static_cast<char*>(c->state_mem);
-        size_t k = 0;
-        auto colf = [&]() { return reinterpret_cast<float*>(base + col * (k++)); };
-        auto colu = [&]() { return reinterpret_cast<uint32_t*>(base + col * (k++)); };
-        PathState& s = c->st;
-        s.ox = colf(); s.oy = colf(); s.oz = colf(); s.dx = colf(); s.dy = colf(); s.dz = colf();
-        s.br = colf(); s.bg = colf(); s.bb = colf();
-        s.lr = colf(); s.lg = colf(); s.lb = colf();
-        s.rng = reinterpret_cast<uint64_t*>(base + col * k);
-        k += 2;
-        s.flags = colu();
-        s.ht = colf(); s.hinst = colu(); s.hprim = colu(); s.hb1 = colf(); s.hb2 = colf();
-        for (int r = 0; r < 2; ++r)
-            for (int a = 0; a < 3; ++a) s.sc[r][a] = colf();
-        for (int a = 0; a < 3; ++a) s.nb[a] = colf();
-        s.nscale = colf();
-        s.npost = colf();
-        s.occ[0] = reinterpret_cast<uint8_t*>(base + col * k);
-        s.occ[1] = s.occ[0] + n_slots;  // the column holds 4 * n_slots bytes
-        k += 1;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->queues), 3 * n_slots * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow_rays), 2 * n_slots * 4 * sizeof(float4)));
-        c->st.shadow_rays = c->shadow_rays;
+        auto align = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t v16 = align(n_slots * sizeof(float4));
+        // q[2][3], hit, L, nee[3]: one float4 per path each; sr[3]: two per path; occ: two bytes; nee queue: one word
+        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + align(n_slots * sizeof(uint32_t));
+        hipError_t e = hipMalloc(&c->state_mem, total);
+        if (e != hipSuccess) {
+            c->state_mem = nullptr;
+            c->error = std::string("hipMalloc of the path state (") + std::to_string(total >> 20) + " MiB): " + hipGetErrorString(e);
+            return PBRS_E_DEVICE;
+        }
+        char* p = static_cast<char*>(c->state_mem);
+        auto take = [&](size_t bytes) { char* r = p; p += bytes; return r; };
+        PathState s{};
+        for (int set = 0; set < 2; ++set)
+            for (int k = 0; k < 3; ++k) s.q[set][k] = reinterpret_cast<float4*>(take(v16));
+        s.hit = reinterpret_cast<float4*>(take(v16));
+        s.L = reinterpret_cast<float4*>(take(v16));
+        for (int k = 0; k < 3; ++k) s.nee[k] = reinterpret_cast<float4*>(take(v16));
+        for (int k = 0; k < 3; ++k) s.sr[k] = reinterpret_cast<float4*>(take(2 * v16));
+        s.occ[0] = reinterpret_cast<uint8_t*>(take(align(2 * n_slots)));
+        s.occ[1] = s.occ[0] + n_slots;
+        c->neeq = reinterpret_cast<uint32_t*>(take(align(n_slots * sizeof(uint32_t))));
+        c->st = s;
         c->cap_slots = n_slots;
     }
     if (n_pixels > c->cap_pixels) {
+        c->cap_pixels = 0;
         if (c->sum) (void)hipFree(c->sum);
         if (c->rgb_dev) (void)hipFree(c->rgb_dev);
         c->sum = nullptr;
@@ -194,8 +191,8 @@ int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* 
     if (p->integrator == PBRS_INTEGRATOR_NORMALS && !c->has_vis_records)
         return fail(c, PBRS_E_INVALID, "the scene's materials carry no pbrs_material::vis_bxdf records");
     if ((uint64_t)p->w * p->h > (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile above 2^28 pixels");
-    // queue entries keep two flag bits next to the slot index
-    if ((uint64_t)p->w * p->h * auto_samples_per_pass(c, p) >= (1ull << 30)) return fail(c, PBRS_E_LIMIT, "tile x samples_per_pass above 2^30 paths");
+    // records keep two flag bits next to the slot index, and 16-byte records are addressed with 32-bit element indices
+    if ((uint64_t)p->w * p->h * auto_samples_per_pass(c, p) >= (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile x samples_per_pass above 2^28 paths");
     return PBRS_OK;
 }
 
@@ -245,7 +242,7 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
         uint64_t target = 128ull << 20;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const uint64_t per_path = 4ull * PBRS_STATE_WORDS + 3ull * 4 + 2ull * 64;  // columns + queues + shadow records
+            const uint64_t per_path = PBRS_STATE_BYTES_PER_PATH;  // path, hit, radiance, shadow-ray and nee records
             // what this context already holds for paths counts as available: the answer must not change between calls
             const uint64_t fit = ((uint64_t)free_b + (uint64_t)c->cap_slots * per_path) / 4 / per_path;
             if (fit < target) target = fit < (4ull << 20) ? (4ull << 20) : fit;
@@ -259,9 +256,9 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
 
 // The traversal kernels are instantiated per scene-feature set (device/shapes.h PBRS_FEAT_*); the instrumented variant
 // exists for the full set only.  k_shadow never evaluates shading frames, so only PBRS_FEAT_ANALYTIC selects it.
-void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uint32_t* queue, const uint32_t* count, uint32_t n_direct, uint32_t* heads) {
+void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* heads) {
 #define PBRS_LAUNCH_EXTEND(ST, F) \
-    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, queue, count, n_direct, heads, c->gcnt)
+    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, set, count, n_direct, heads, c->gcnt)
     if (stats) {
         PBRS_LAUNCH_EXTEND(true, PBRS_FEAT_ALL);
         return;
@@ -311,8 +308,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     // work-fetch heads of k_extend / k_shadow: kHeadWords words per bounce (one head per queue segment, kernels.h)
     uint32_t* xhead = c->counters + 3 * stride;
     uint32_t* shead = xhead + stride * kHeadWords;
-    uint32_t* q[2] = {c->queues, c->queues + c->cap_slots};
-    uint32_t* neeq = c->queues + 2 * c->cap_slots;
+    uint32_t* neeq = c->neeq;
     HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(uint32_t), c->stream));
     if (tm.begin(0)) return fail(c, PBRS_E_DEVICE, "event record failed");
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, c->st, rc);
@@ -323,15 +319,16 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
                                : rc.integrator >= PBRS_INTEGRATOR_MATERIALS ? 1u  // the visualisers: one cast, no lights
                                                                             : rc.max_depth;
     for (uint32_t b = 0; b < n_bounces; ++b) {
-        const uint32_t* qin = b == 0 ? nullptr : q[b & 1];
+        // bounce b reads the path records of set b & 1 (k_raygen wrote set 0) and k_shade writes set (b + 1) & 1; the
+        // queue length of bounce 0 is the pass size, later ones are counted on the device
+        const uint32_t* cnt_in = b == 0 ? nullptr : act + b;
         if (tm.begin(1)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        launch_extend(c, stats, pgrid, lds, qin, act + b, N, xhead + b * kHeadWords);
+        launch_extend(c, stats, pgrid, lds, b & 1u, cnt_in, N, xhead + b * kHeadWords);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
         {
 #define PBRS_LAUNCH_SHADE(I, T)                                                                                                  \
-    hipLaunchKernelGGL((k_shade<I, T>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, qin, act + b, N, q[(b + 1) & 1], \
-                       act + b + 1, neeq, ns + b)
+    hipLaunchKernelGGL((k_shade<I, T>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, cnt_in, N, act + b + 1, neeq, ns + b)
             const bool direct = rc.integrator == PBRS_INTEGRATOR_DIRECT;
             if (rc.integrator == PBRS_INTEGRATOR_MATERIALS) {
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false);
@@ -360,9 +357,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
 }
 
 int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, float* rgb_device) {
+    HIPCHK(c, hipSetDevice(c->device));  // before check_params: the automatic pass size reads THIS device's free memory
     int rcode = check_params(c, cam, p);
     if (rcode) return rcode;
-    HIPCHK(c, hipSetDevice(c->device));
     const uint32_t P = p->w * p->h;
     const uint32_t spp = p->strata_x * p->strata_y;
     const uint32_t K = auto_samples_per_pass(c, p);
@@ -445,17 +442,19 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return PBRS_E_DEVICE;
     pbrs_ctx* c = new pbrs_ctx();
     c->device = device_ordinal;
-    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
-        delete c;
-        return PBRS_E_DEVICE;
-    }
+    // every failure below leaves through pbrs_destroy, which releases whatever had been created by then
+    bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess;
     c->stream = c->own_stream;
-    c->total_ev.resize(2);
-    if (hipEventCreate(&c->total_ev[0]) != hipSuccess || hipEventCreate(&c->total_ev[1]) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->world), (size_t)PBRS_WORLD_WORDS * PBRS_TRAVERSAL_LANES * sizeof(uint32_t)) != hipSuccess) {
-        delete c;
+    for (int k = 0; ok && k < 2; ++k) {
+        hipEvent_t ev = nullptr;
+        ok = hipEventCreate(&ev) == hipSuccess;
+        if (ok) c->total_ev.push_back(ev);
+    }
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&c->world), (size_t)PBRS_WORLD_WORDS * PBRS_TRAVERSAL_LANES * sizeof(uint32_t)) == hipSuccess;
+    if (!ok) {
+        pbrs_destroy(c);
         return PBRS_E_DEVICE;
     }
     *out = c;
@@ -465,7 +464,7 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
 void pbrs_destroy(pbrs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     free_work(c);
     if (c->counters) (void)hipFree(c->counters);
@@ -664,6 +663,7 @@ int pbrs_render_tile_device(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_rend
 int pbrs_render_tile(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, float* rgb_out_host, pbrs_stats* stats_out) {
     if (!c) return PBRS_E_INVALID;
     if (!rgb_out_host) return fail(c, PBRS_E_INVALID, "null output");
+    HIPCHK(c, hipSetDevice(c->device));
     int rc = check_params(c, cam, p);
     if (rc) return rc;
     rc = ensure_work(c, (size_t)p->w * p->h * auto_samples_per_pass(c, p), (size_t)p->w * p->h);
@@ -721,10 +721,10 @@ int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const flo
 
 int pbrs_camera_rays(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, uint32_t sample_index, float* origins_out, float* dirs_out) {
     if (!c) return PBRS_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     int rc = check_params(c, cam, p);
     if (rc) return rc;
     if (!origins_out || !dirs_out) return fail(c, PBRS_E_INVALID, "null output");
-    HIPCHK(c, hipSetDevice(c->device));
     const uint32_t P = p->w * p->h;
     rc = ensure_work(c, P, P);
     if (rc) return rc;
@@ -769,10 +769,10 @@ int pbrs_numeric_eval(pbrs_ctx* c, uint32_t fn, uint32_t n, const float* x, cons
 
 int pbrs_render_sample_radiance(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, uint32_t sample_index, float* rgb_out_host) {
     if (!c) return PBRS_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     int rc = check_params(c, cam, p);
     if (rc) return rc;
     if (!rgb_out_host) return fail(c, PBRS_E_INVALID, "null output");
-    HIPCHK(c, hipSetDevice(c->device));
     const uint32_t P = p->w * p->h;
     rc = ensure_work(c, P, P);
     if (rc) return rc;

@@ -132,6 +132,51 @@ def test_materials_and_lights_outside_the_baseline_scenes(gpu_ctx):
         assert (bits(img)[~nan_ref] == bits(ref)[~nan_ref]).all(), variant
 
 
+def _parallel_quad_scene(textured):
+    """ParallelQuad INSTANCES in front of the camera (shape/src/simple.rs:120-163): the Interaction that k_shade rebuilds
+    for them (`quad_isect`: pos = origin + u a + v b with the unsigned u, v of defect D1, uv = (u, v), dpdu = side_u) is
+    what every shaded pixel of a quad goes through.  The camera sees the quads' own quadrant and, past their origins, the
+    mirrored quadrants D1 creates; the reference would panic there (its `accurate_hit` assert) — the oracle counts
+    those and carries on with the arithmetic result, which is what the device computes."""
+    from pbrs_amd.spec import SceneBuilder, Transform, deg
+    sb = SceneBuilder()
+    floor = sb.lambertian((0.5, 0.5, 0.45))
+    sb.instance(scenes.quad_mesh(sb, (-8, 0, -8), (8, 0, -8), (-8, 0, 8), (8, 0, 8), (0, 1, 0)), floor)
+    tex = sb.checker((0.1, 0.1, 0.3), (0.9, 0.8, 0.6)) if textured else None  # reads the quad's uv
+    sb.instance(sb.quad((-0.5, 0.6, 1.0), (1.6, 0.0, 0.3), (0.0, 1.4, 0.2)), sb.lambertian(tex if textured else (0.7, 0.3, 0.2)))
+    sb.instance(sb.quad((0.0, 0.0, 0.0), (1.2, 0.0, 0.0), (0.0, 0.0, 1.2)), sb.plastic((0.2, 0.6, 0.3), (0.4, 0.4, 0.4), 0.15, True),
+                Transform().rotate_y(deg(25.0)).rotate_x(deg(-20.0)).translate((-2.4, 1.2, 0.5)))
+    sb.instance(sb.quad((2.0, 0.4, 0.0), (0.0, 1.5, 0.0), (0.9, 0.0, 0.9)), sb.mirror((0.9, 0.9, 0.9)))
+    e = (9.0, 8.0, 7.0)
+    light = sb.sphere((0.5, 5.0, -1.0), 0.7)
+    sb.instance(light, sb.diffuse_light(e))
+    sb.area_light(e, light)
+    sb.env = (0.2, 0.25, 0.3)
+    sb.set_camera(80, 56, deg(50.0), (0.2, 2.2, -6.0), (0, 1.0, 0.8))
+    return sb
+
+
+@pytest.mark.parametrize("textured", [False, True])
+@pytest.mark.parametrize("integrator", ["path", "direct"])
+def test_parallel_quad_instances_match_oracle(gpu_ctx, textured, integrator):
+    sb = _parallel_quad_scene(textured)
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    ref, ost = osc.render(2, 2, 6, 17, integrator=integrator)
+    img, st = gpu_ctx.render(2, 2, 6, 17, integrator=integrator, counters=True)
+    assert st["quads"] > 0 and ost["tlas_ties"] == 0
+    assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    nan = np.isnan(ref)
+    assert (nan == np.isnan(img)).all()
+    assert (bits(img)[~nan] == bits(ref)[~nan]).all()
+    # quads fill a good part of the frame: their pixels differ from a render without them
+    if integrator == "path" and not textured:
+        h0, _, _ = osc.intersect(*osc.camera_rays(0, 1, 1, 17), np.full(80 * 56, np.inf, dtype=np.float32))
+        kinds = sb.build()
+        quad_insts = [i for i in range(kinds.n_instances) if kinds.shapes[kinds.instances[i].shape].kind == 1]
+        assert np.isin(h0["inst"], quad_insts).mean() > 0.05
+
+
 def _specular_scene(variant):
     """Mirror sphere, glass sphere, mirror quad mesh and a dielectric-coated (uber: transmit + reflect) box in front of the
     camera, so that direct_lighting_integrator's specular arm (src/directlighting.rs:31-41) is taken for many pixels."""
