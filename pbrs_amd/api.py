@@ -71,7 +71,7 @@ class RenderParams(C.Structure):
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("inst", np.uint32), ("prim", np.uint32), ("b1", np.float32), ("b2", np.float32)])
 NUMERIC_FNS = {"sin": 0, "cos": 1, "tan": 2, "atan": 3, "atan2": 4, "acos": 5, "exp": 6, "ln": 7, "hypot": 8, "div": 9,
-               "sqrt": 10, "asin": 11, "powi": 12, "fract": 13, "floor": 14}
+               "sqrt": 10, "asin": 11, "powi": 12, "fract": 13, "floor": 14, "box_quotient": 15}
 
 GPU_SYMBOLS = ["pbrs_create", "pbrs_destroy", "pbrs_last_error", "pbrs_set_stream", "pbrs_upload_scene", "pbrs_render_tile",
                "pbrs_render_tile_device", "pbrs_collect_stats", "pbrs_intersect_rays", "pbrs_camera_rays", "pbrs_numeric_eval",

@@ -51,6 +51,9 @@ struct DevScene {
 // Scene features the traversal kernels are specialised on (pbrs_upload_scene derives them from the arrays it checks).
 // Code a scene cannot reach still costs registers and issue slots on every wave, so each combination is its own
 // instantiation: a mesh-only scene whose meshes all carry a PBRS_MESH_*_SHADING_OK flag runs the leanest one.
+// pbrs_instance::flags bit set by pbrs_upload_scene on the device copy (not part of the ABI): the 3x3 part of `inv` is
+// bit-exactly the identity, i.e. the instance is only translated (traverse.h, enter_instance)
+#define PBRS_INSTANCE_TRANSLATION 0x100u
 #define PBRS_FEAT_ANALYTIC 1u       // some instance is an analytic shape (sphere, disk, quad, cuboid, triangle)
 #define PBRS_FEAT_SHADING_CHECK 2u  // some mesh needs the tangent check of blas.rs:193-200 evaluated per candidate hit
 #define PBRS_FEAT_FLAT_TLAS 4u      // the leaf copies at DevScene::flat_off are built: rays on the division-free box test scan the TLAS leaves

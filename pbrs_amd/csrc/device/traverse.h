@@ -14,8 +14,10 @@
 // instructions on gfx950.  `(float)((double)n * R)` with R = rn64(1/(double)d) IS the correctly rounded
 // f32 quotient whenever no f32 overflow/underflow is involved: the f64 product is within 2^-52 of n/d,
 // while n/d (a ratio of two 24-bit significands) is either exactly an f32 or at least 2^-49 (relative)
-// away from every f32 rounding boundary, so the two round to the same f32.  R is computed once per ray
-// and per instance; each quotient is then cvt + v_mul_f64 + cvt.  Lanes whose ray leaves the guarded
+// away from every f32 rounding boundary, so the two round to the same f32.  The argument needs R only to within a few
+// ulp64 of 1/d, so R comes from v_rcp_f64 and two Newton steps (recip64: the refined reciprocal of the compiler's own
+// f64 division, <= 1 ulp64, the product then within 2^-51 of n/d) instead of a full IEEE division (11 f64 instructions).
+// R is computed once per ray and per instance; each quotient is then cvt + v_mul_f64 + cvt.  Lanes whose ray leaves the guarded
 // range (a zero / denormal / huge direction component, an origin component that is tiny but non-zero)
 // take the reference's literal divisions instead; pbrs_upload_scene checks the node coordinates once.
 #pragma once
@@ -36,6 +38,18 @@ PD uint32_t origin_in_range(float x) {  // zero, or 2^-60 <= |x| <= 2^40
     uint32_t e = u >> 23;
     return ((u == 0u) | (e - (127u - 60u) <= 100u)) ? 1u : 0u;
 }
+// 1 / x for a normal f64 x of moderate exponent (|x| in [2^-40, 2^40] here): v_rcp_f64 is good to about 2^-26, each
+// Newton step r <- r + r (1 - x r) squares the error; after two the result is within one ulp64.
+PD double recip64(double x) {
+#ifdef PBRS_IEEE_RECIP64
+    return 1.0 / x;
+#else
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    return r;
+#endif
+}
 PD RaySpace make_space(f3 o, f3 d, bool scene_ok) {
     RaySpace r;
     r.o = o;
@@ -44,9 +58,9 @@ PD RaySpace make_space(f3 o, f3 d, bool scene_ok) {
               origin_in_range(o.y) & origin_in_range(o.z)) != 0u;
     r.rx = r.ry = r.rz = 0.0;
     if (r.fast) {
-        r.rx = 1.0 / (double)d.x;
-        r.ry = 1.0 / (double)d.y;
-        r.rz = 1.0 / (double)d.z;
+        r.rx = recip64((double)d.x);
+        r.ry = recip64((double)d.y);
+        r.rz = recip64((double)d.z);
     }
     return r;
 }
@@ -94,6 +108,17 @@ PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, 
     if ((in.flags & PBRS_INSTANCE_IDENTITY) && C.fast && C.o.x != 0.0f && C.o.y != 0.0f && C.o.z != 0.0f) return false;
     save_world(stk, C);
     f3 oo = xf_apply(in.inv, C.o, 1.0f);
+    // A pure translation (the 3x3 part of `inverse` bit-exactly the identity, flagged at upload): the Mat4 product
+    // returns the direction's own bits — 1*x + 0*y + 0*z + t*0 with x finite and non-zero, which C.fast guarantees — so
+    // the reciprocals stay; only the origin moves (and must stay inside the guarded range).
+    if (need_slab && (in.flags & PBRS_INSTANCE_TRANSLATION) && C.fast) {
+        C.o = oo;
+        if (!(origin_in_range(oo.x) & origin_in_range(oo.y) & origin_in_range(oo.z))) {
+            C.fast = false;
+            C.rx = C.ry = C.rz = 0.0;
+        }
+        return true;
+    }
     f3 od = xf_apply(in.inv, C.d, 0.0f);
     if (need_slab) {
         C = make_space(oo, od, S.fast_slab != 0);

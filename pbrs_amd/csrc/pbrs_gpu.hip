@@ -581,8 +581,14 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             if (!(nodes[i].b & PBRS_LEAF_FLAG)) nodes[i].a += (uint32_t)blas_off;  // right child; the left one is i + 1
         if ((rc = upload(c, nodes.data(), nodes.size(), &S.nodes))) return rc;
         std::vector<pbrs_instance> inst(d->instances, d->instances + d->n_instances);
-        for (pbrs_instance& in : inst)
+        for (pbrs_instance& in : inst) {
             if (in.shape_kind == PBRS_SHAPE_MESH) in.blas_root += (uint32_t)blas_off;
+            bool linear_identity = true;  // bit patterns: -0.0 would not do
+            for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < 3; ++k) linear_identity = linear_identity && pn_bits(in.inv[r][k]) == pn_bits(r == k ? 1.0f : 0.0f);
+            in.flags &= ~PBRS_INSTANCE_TRANSLATION;
+            if (linear_identity) in.flags |= PBRS_INSTANCE_TRANSLATION;
+        }
         if ((rc = upload(c, inst.data(), inst.size(), &S.inst))) return rc;
     }
     if ((rc = upload(c, d->shapes, d->n_shapes, &S.shapes))) return rc;
@@ -748,7 +754,7 @@ int pbrs_camera_rays(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_para
 int pbrs_numeric_eval(pbrs_ctx* c, uint32_t fn, uint32_t n, const float* x, const float* y, float* out) {
     if (!c) return PBRS_E_INVALID;
     if (n == 0) return PBRS_OK;
-    if (!x || !out || fn > 14) return fail(c, PBRS_E_INVALID, "bad numeric_eval arguments");
+    if (!x || !out || fn > 15) return fail(c, PBRS_E_INVALID, "bad numeric_eval arguments");
     HIPCHK(c, hipSetDevice(c->device));
     float *d_x = nullptr, *d_y = nullptr, *d_r = nullptr;
     auto cleanup = [&]() { (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_r); };
