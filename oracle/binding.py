@@ -43,7 +43,8 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libpbrs_oracle.so")
+        # PBRS_ORACLE_LIB: the sanitizer build (tools/cpu_asan.sh: make -C oracle asan)
+        path = os.environ.get("PBRS_ORACLE_LIB") or os.path.join(_HERE, "libpbrs_oracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

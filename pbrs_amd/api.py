@@ -92,7 +92,8 @@ def lib_paths():
 def host_lib():
     global _host
     if _host is None:
-        path = lib_paths()[0]
+        # PBRS_HOST_LIB: the sanitizer build of the host library (tools/cpu_asan.sh: make -C pbrs_amd/csrc host-asan)
+        path = os.environ.get("PBRS_HOST_LIB") or lib_paths()[0]
         if not os.path.exists(path):
             raise PbrsError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (make -C pbrs_amd/csrc)")
         L = C.CDLL(path)
