@@ -25,7 +25,8 @@ struct PathState {
     //   q[.][1][i] = dir.xyz,    RNG state, low word
     //   q[.][2][i] = beta.xyz,   RNG state, high word
     float4* q[2][3];
-    float4* hit;  // [i] = t, inst (0xffffffff: miss), prim, -   written by k_extend at the ray's queue position
+    float4* hit;  // [i] = t, inst (0xffffffff: miss), prim, shading class   written by k_extend at the ray's queue position
+    uint32_t* perm;  // scenes with several shading classes: k_shade's lane j shades the path at queue position perm[j] (k_class_sort)
     float4* L;    // [slot] = radiance.xyz, w: the direct integrator's 1 / mass (src/directlighting.rs:37), else unused
     // Next-event estimation hand-off.  Shadow rays by position j in the bounce's shadow queue:
     //   sr[0][j] = origin.xyz, t_max        sr[1][j] = dir.xyz, item
@@ -37,7 +38,7 @@ struct PathState {
     float4* nee[3];   // [slot]: c1.xyz, 1 / light_pdf | c2.xyz, post factor | beta at the time of the estimate, -
     uint8_t* occ[2];  // [slot], written by k_shadow: 1 = the ray is occluded
 };
-#define PBRS_STATE_BYTES_PER_PATH (2u * 48u + 16u + 16u + 2u * 48u + 48u + 2u + 4u)  // records above + the nee queue entry
+#define PBRS_STATE_BYTES_PER_PATH (2u * 48u + 16u + 4u + 16u + 2u * 48u + 48u + 2u + 4u)  // records above + the nee queue entry
 
 struct RenderConst {
     pbrs_camera cam;
@@ -267,9 +268,9 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
                                                uint32_t* next, GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t n = count ? *count : n_direct;
-    const float4* __restrict__ q0 = st.q[set][0];
-    const float4* __restrict__ q1 = st.q[set][1];
-    LaneStack stk{lds_stack + threadIdx.x, S.world + (blockIdx.x * PBRS_TRAVERSAL_BLOCK + threadIdx.x) * 3u};
+    const float4* q0 = st.q[set][0];
+    const float4* q1 = st.q[set][1];
+    LaneStack stk{lds_stack + threadIdx.x, q0, q1, 0u};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
@@ -285,13 +286,16 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
                 nhit += h.inst != 0xffffffffu ? 1u : 0u;
                 // k_shade rebuilds the Interaction from (t, inst, prim): the barycentrics are recomputed there, as the
                 // reference's intersect does for the winning primitive
-                st.hit[item] = make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), 0.0f);
+                // the 4th word names the hit's shading class (pbrs_upload_scene: DevScene::inst_class), 0 for a miss
+                const uint32_t cls = (S.n_classes > 1u && h.inst != 0xffffffffu) ? S.inst[h.inst].pad[0] : 0u;
+                st.hit[item] = make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), __uint_as_float(cls));
                 walk.mode = PBRS_WALK_IDLE;
             }
             if (work.left()) {
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
                     item = idx;
+                    stk.item = idx;
                     const float4 a = q0[idx], b = q1[idx];
                     walk.start(S, xyz(a), xyz(b), pn_inf(), stk);
                     nrays++;
@@ -330,7 +334,7 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 // ---- shade -----------------------------------------------------------------------------------------------------
 template <uint32_t INTEG, bool TEX>
 __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
-                                              uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count) {
+                                              uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count, uint32_t sorted) {
     // per-hit lobe lists of textured materials (Bsdf::hit_lobe / hit_albedo); absent from the untextured instantiation
     __shared__ uint32_t s_hit_lobe[TEX ? PBRS_MAX_BXDFS * 256 : 1];
     __shared__ float s_hit_albedo[TEX ? 3 * PBRS_MAX_BXDFS * 256 : 1];
@@ -353,7 +357,9 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
     uint32_t next_spec = 0;
     if (valid) {
         const uint32_t set = bounce & 1u;
-        const float4 r0 = st.q[set][0][i], r1 = st.q[set][1][i], r2 = st.q[set][2][i], rh = st.hit[i];
+        // several shading classes: lanes take the paths in class order (k_class_sort), so that a wave runs one material's code
+        const uint32_t src = sorted ? st.perm[i] : i;
+        const float4 r0 = st.q[set][0][src], r1 = st.q[set][1][src], r2 = st.q[set][2][src], rh = st.hit[src];
         slot = __float_as_uint(r0.w) & PBRS_SLOT_MASK;
         const float4 rl = st.L[slot];
         f3 o = xyz(r0), d = xyz(r1);
@@ -731,6 +737,59 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
 #endif
 }
 
+// ---- class sort ------------------------------------------------------------------------------------------------
+// A wave of k_shade that holds paths on different kinds of material runs every kind's code one after the other with most
+// lanes masked (C3: 30 of 64 lanes active on average).  Scenes with several shading classes (materials with the same
+// lobe signature, pbrs_upload_scene) therefore get their bounce queues ordered by class before shading: a stable
+// counting sort of the hit records' class word within tiles of PBRS_SORT_TILE queue positions (one block per tile), which
+// writes the permutation k_shade reads its paths through.  The records themselves stay where they are (k_shade gathers
+// 4 x 16 bytes per path; inside a class the order is the queue's, so the gathers stay near-sequential) and tiles keep
+// the spatial order of the queue at large.  The result of a path does not depend on which lane shades it.
+#define PBRS_SORT_TILE 16384u
+#define PBRS_MAX_CLASSES 16u
+__global__ void __launch_bounds__(256) k_class_sort(PathState st, const uint32_t* count, uint32_t n_direct) {
+    const uint32_t n = count ? *count : n_direct;
+    const uint32_t base = blockIdx.x * PBRS_SORT_TILE;
+    if (base >= n) return;
+    const uint32_t end = base + PBRS_SORT_TILE < n ? base + PBRS_SORT_TILE : n;
+    __shared__ uint32_t s_tot[PBRS_MAX_CLASSES];     // class sizes in the tile, then their running write offsets
+    __shared__ uint32_t s_wave[4][PBRS_MAX_CLASSES];  // per iteration: class counts of each wave
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256u) atomicAdd(&s_tot[__float_as_uint(st.hit[i].w) & (PBRS_MAX_CLASSES - 1u)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive prefix over the classes
+        uint32_t run = base;
+        for (uint32_t c = 0; c < PBRS_MAX_CLASSES; ++c) {
+            const uint32_t k = s_tot[c];
+            s_tot[c] = run;
+            run += k;
+        }
+    }
+    __syncthreads();
+    for (uint32_t it = base; it < end; it += 256u) {  // every thread of the block takes part in the barriers
+        const uint32_t i = it + threadIdx.x;
+        const bool valid = i < end;
+        const uint32_t cls = valid ? (__float_as_uint(st.hit[i].w) & (PBRS_MAX_CLASSES - 1u)) : 0xffffffffu;
+        uint32_t rank = 0;
+        for (uint32_t c = 0; c < PBRS_MAX_CLASSES; ++c) {
+            const uint64_t m = __ballot(cls == c);
+            if (cls == c) rank = lane_prefix(m);
+            if (lane == 0) s_wave[wave][c] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = s_tot[cls] + rank;
+            for (uint32_t w = 0; w < wave; ++w) pos += s_wave[w][cls];
+            st.perm[pos] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] += s_wave[0][threadIdx.x] + s_wave[1][threadIdx.x] + s_wave[2][threadIdx.x] + s_wave[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
 // ---- shadow ----------------------------------------------------------------------------------------------------
 // One work item per shadow ray (persistent, same refill scheme as k_extend); writes one occlusion byte.
 template <bool STATS, uint32_t FEAT>
@@ -738,7 +797,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
                                                GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t n = count[1];  // high half of the packed (nee paths, shadow rays) counter
-    LaneStack stk{lds_stack + threadIdx.x, S.world + (blockIdx.x * PBRS_TRAVERSAL_BLOCK + threadIdx.x) * 3u};
+    LaneStack stk{lds_stack + threadIdx.x, st.sr[0], st.sr[1], 0u};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
@@ -770,6 +829,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(Dev
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
                     rec = idx;
+                    stk.item = idx;
                     const float4 q0 = st.sr[0][idx], q1 = st.sr[1][idx];
                     item = __float_as_uint(q1.w);
                     walk.start(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, stk);
@@ -830,10 +890,10 @@ __global__ void __launch_bounds__(256) k_finalize(const float* sum, float* rgb, 
 }
 
 // ---- parity-harness kernels --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, const float* origins, const float* dirs, const float* tmax,
+__global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, const float4* origins, const float4* dirs, const float* tmax,
                                                        pbrs_hit_record* hits, uint8_t* occluded) {
     extern __shared__ uint32_t lds_stack[];
-    LaneStack stk{lds_stack + threadIdx.x, S.world + (blockIdx.x * PBRS_TRAVERSAL_BLOCK + threadIdx.x) * 3u};
+    LaneStack stk{lds_stack + threadIdx.x, origins, dirs, 0u};
     Cnt<false> cnt;
     // grid <= PBRS_PERSISTENT_BLOCKS; whole blocks stay in the loop together (the walks share work across a wave)
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
@@ -842,9 +902,10 @@ __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, 
         f3 o = gray(0.0f), d = gray(1.0f);
         float t_max = 0.0f;
         if (active) {
-            o = ld3(origins + 3 * i);
-            d = ld3(dirs + 3 * i);
+            o = xyz(origins[i]);
+            d = xyz(dirs[i]);
             t_max = tmax[i];
+            stk.item = i;
         }
         if (hits) {
             Hit h;

@@ -45,7 +45,10 @@ struct DevScene {
     const uint32_t* tex_words;
     uint32_t env_kind, env_texture;
     float env_scale[3];
-    uint4* world;        // PBRS_TRAVERSAL_LANES records of 3 x 16 bytes of per-lane scratch (LaneStack::world)
+    // Shading classes: materials with the same lobe signature (kinds, Fresnel forms, textured or not) share one; the device
+    // copy of an instance carries its material's class in pad[0].  More than one class with lobes: the bounce queues are
+    // ordered by class before k_shade (kernels.h, k_class_sort).
+    uint32_t n_classes;
 };
 
 // Scene features the traversal kernels are specialised on (pbrs_upload_scene derives them from the arrays it checks).
@@ -406,11 +409,12 @@ PD bool mesh_tri_pred(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max) {
 // The traversal kernels are persistent: at most this many blocks, each lane keeps pulling rays (kernels.h).
 #define PBRS_PERSISTENT_BLOCKS 1536
 #define PBRS_TRAVERSAL_LANES (PBRS_PERSISTENT_BLOCKS * PBRS_TRAVERSAL_BLOCK)
-#define PBRS_WORLD_WORDS 12
 struct LaneStack {
-    uint32_t* base;   // &lds[threadIdx.x]
-    uint4* world;     // &S.world[(blockIdx.x * 256 + threadIdx.x) * 3]: the lane's world-space ray waits in this 48-byte
-                      // record while the lane walks an instance (three 16-byte accesses, L2-resident; 13 VGPRs less)
+    uint32_t* base;    // &lds[threadIdx.x]
+    // where the lane's own ray can be read again: origin.xyz at ro[item], direction.xyz at rd[item] (traverse.h, reload_world)
+    const float4* ro;
+    const float4* rd;
+    uint32_t item;
     PD void put(int level, uint32_t v) { base[level * PBRS_TRAVERSAL_BLOCK] = v; }
     PD uint32_t get(int level) const { return base[level * PBRS_TRAVERSAL_BLOCK]; }
 };

@@ -64,24 +64,12 @@ PD RaySpace make_space(f3 o, f3 d, bool scene_ok) {
     }
     return r;
 }
-// The world-space ray of a lane that is inside an instance waits in the lane's scratch record (LaneStack::world).
-// `fast` is not stored: make_space leaves the reciprocals at 0.0 exactly when it is false, and 1/d is never 0.
-PD void save_world(LaneStack stk, const RaySpace& r) {
-    stk.world[0] = make_uint4(pn_bits(r.o.x), pn_bits(r.o.y), pn_bits(r.o.z), pn_bits(r.d.x));
-    stk.world[1] = make_uint4(pn_bits(r.d.y), pn_bits(r.d.z), (uint32_t)__double2loint(r.rx), (uint32_t)__double2hiint(r.rx));
-    stk.world[2] = make_uint4((uint32_t)__double2loint(r.ry), (uint32_t)__double2hiint(r.ry), (uint32_t)__double2loint(r.rz),
-                              (uint32_t)__double2hiint(r.rz));
-}
-PD RaySpace load_world(LaneStack stk) {
-    const uint4 a = stk.world[0], b = stk.world[1], c = stk.world[2];
-    RaySpace r;
-    r.o = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-    r.d = mk3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
-    r.rx = __hiloint2double((int)b.w, (int)b.z);
-    r.ry = __hiloint2double((int)c.y, (int)c.x);
-    r.rz = __hiloint2double((int)c.w, (int)c.z);
-    r.fast = r.rx != 0.0;
-    return r;
+// The world-space ray of a lane that is inside an instance is not kept anywhere: when the lane comes back out it reads
+// its ray record again (LaneStack::ro / rd at the lane's item — the 32 bytes its walk started from, usually still in L2)
+// and rebuilds the space with the same operations, hence the same bits, as ClosestWalk::start did.
+PD RaySpace reload_world(const DevScene& S, LaneStack stk) {
+    const float4 a = stk.ro[stk.item], b = stk.rd[stk.item];
+    return make_space(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), S.fast_slab != 0);
 }
 PD float qdiv(float n, double r) { return (float)((double)n * r); }
 // geometry/src/bvh.rs:84-99 (same min/max/NaN conventions as dmath.h::slab_test)
@@ -106,7 +94,6 @@ PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
 // Returns false when the lane's ray is unchanged (C still is the world ray).
 PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, bool need_slab, LaneStack stk) {
     if ((in.flags & PBRS_INSTANCE_IDENTITY) && C.fast && C.o.x != 0.0f && C.o.y != 0.0f && C.o.z != 0.0f) return false;
-    save_world(stk, C);
     f3 oo = xf_apply(in.inv, C.o, 1.0f);
     // A pure translation (the 3x3 part of `inverse` bit-exactly the identity, flagged at upload): the Mat4 product
     // returns the direction's own bits — 1*x + 0*y + 0*z + t*0 with x finite and non-zero, which C.fast guarantees — so
@@ -263,7 +250,7 @@ struct FlatScan {
 template <bool STATS, uint32_t FEAT>
 struct ClosestWalk {
     RaySpace C;  // the space the lane is walking in (the world ray in the TLAS, the instance's ray below a TLAS leaf): one
-                 // box-test call serves lanes in either tree.  The world ray is parked in the lane's scratch meanwhile.
+                 // box-test call serves lanes in either tree.  The world ray is read again on the way out (reload_world).
     Hit best;       // best.t stays +inf until the first candidate: `!(best.t < t)` then accepts it, as Option::None does
     float t_max, lt, mt, mb1, mb2;  // lt: the cloned ray's t_max inside intersect_bvh; mt: outer_hit.ray_t
     uint32_t mprim, cur_inst;
@@ -271,7 +258,7 @@ struct ClosestWalk {
     uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or leaf_a = the analytic shape
     int sp, blas_base;
     uint32_t cand;        // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
-    bool in_blas, moved;  // moved: C differs from the parked world ray
+    bool in_blas, moved;  // moved: C is not the world ray
     uint32_t mode;
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
@@ -369,7 +356,7 @@ struct ClosestWalk {
         mode = PBRS_WALK_NODE;
         if (in_blas) {  // intersect_bvh / the shape returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
             in_blas = false;
-            if (moved) C = load_world(stk);
+            if (moved) C = reload_world(S, stk);
             // a mesh candidate always has t < inf (it beat outer_hit.ray_t = inf); an analytic one may sit at t == +inf
             // (x / 0 with an infinite extent), so those are flagged
             if (mt < pn_inf() || (inst_info & 0x80000000u)) {
@@ -615,7 +602,7 @@ struct AnyWalk {
         mode = PBRS_WALK_NODE;
         if (in_blas) {
             in_blas = false;
-            if (moved) C = load_world(stk);
+            if (moved) C = reload_world(S, stk);
             return;
         }
         const pbrs_instance& in = S.inst[leaf_a];

@@ -8,7 +8,9 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see include/pbrs_numeric.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,7 +51,6 @@ struct pbrs_ctx {
     void* state_mem = nullptr;    // every per-path array of PathState, carved out of one allocation
     PathState st{};
     uint32_t* neeq = nullptr;     // cap_slots: slots of the paths whose estimate waits for two shadow rays
-    uint4* world = nullptr;       // PBRS_TRAVERSAL_LANES x 48 bytes: parked world rays of the traversal lanes
     uint32_t* counters = nullptr; // kCounterWords: act, ns (u64), extend work heads, shadow work heads
     float* sum = nullptr;         // 3 * cap_pixels, planar
     float* rgb_dev = nullptr;     // 3 * cap_pixels, row-major (for the host-output variant)
@@ -63,6 +64,7 @@ struct pbrs_ctx {
     bool pending_counters = false, pending_times = false;
     bool textured = false;  // the uploaded scene evaluates non-Solid textures: k_shade<.., true>
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
+    bool sort_classes = true;      // PBRS_SORT_CLASSES=0 in the environment turns the class sort off (A/B timing)
     uint64_t pending_closest = 0;
 };
 
@@ -126,7 +128,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         auto align = [](size_t b) { return (b + 255) / 256 * 256; };
         const size_t v16 = align(n_slots * sizeof(float4));
         // q[2][3], hit, L, nee[3]: one float4 per path each; sr[3]: two per path; occ: two bytes; nee queue: one word
-        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + align(n_slots * sizeof(uint32_t));
+        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + 2 * align(n_slots * sizeof(uint32_t));
         hipError_t e = hipMalloc(&c->state_mem, total);
         if (e != hipSuccess) {
             c->state_mem = nullptr;
@@ -145,6 +147,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         s.occ[0] = reinterpret_cast<uint8_t*>(take(align(2 * n_slots)));
         s.occ[1] = s.occ[0] + n_slots;
         c->neeq = reinterpret_cast<uint32_t*>(take(align(n_slots * sizeof(uint32_t))));
+        s.perm = reinterpret_cast<uint32_t*>(take(align(n_slots * sizeof(uint32_t))));
         c->st = s;
         c->cap_slots = n_slots;
     }
@@ -326,9 +329,13 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         launch_extend(c, stats, pgrid, lds, b & 1u, cnt_in, N, xhead + b * kHeadWords);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
+        // several shading classes (and an integrator that shades): order the queue by class first; counted as shade time
+        const uint32_t sorted = (c->S.n_classes > 1u && rc.integrator <= PBRS_INTEGRATOR_DIRECT && c->sort_classes) ? 1u : 0u;
+        if (sorted)
+            hipLaunchKernelGGL(k_class_sort, dim3((N + PBRS_SORT_TILE - 1) / PBRS_SORT_TILE), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
         {
 #define PBRS_LAUNCH_SHADE(I, T)                                                                                                  \
-    hipLaunchKernelGGL((k_shade<I, T>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, cnt_in, N, act + b + 1, neeq, ns + b)
+    hipLaunchKernelGGL((k_shade<I, T>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, cnt_in, N, act + b + 1, neeq, ns + b, sorted)
             const bool direct = rc.integrator == PBRS_INTEGRATOR_DIRECT;
             if (rc.integrator == PBRS_INTEGRATOR_MATERIALS) {
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false);
@@ -445,14 +452,14 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     // every failure below leaves through pbrs_destroy, which releases whatever had been created by then
     bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess;
     c->stream = c->own_stream;
+    if (const char* e = getenv("PBRS_SORT_CLASSES")) c->sort_classes = std::atoi(e) != 0;
     for (int k = 0; ok && k < 2; ++k) {
         hipEvent_t ev = nullptr;
         ok = hipEventCreate(&ev) == hipSuccess;
         if (ok) c->total_ev.push_back(ev);
     }
     ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) == hipSuccess &&
-         hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) == hipSuccess &&
-         hipMalloc(reinterpret_cast<void**>(&c->world), (size_t)PBRS_WORLD_WORDS * PBRS_TRAVERSAL_LANES * sizeof(uint32_t)) == hipSuccess;
+         hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) == hipSuccess;
     if (!ok) {
         pbrs_destroy(c);
         return PBRS_E_DEVICE;
@@ -469,7 +476,6 @@ void pbrs_destroy(pbrs_ctx* c) {
     free_work(c);
     if (c->counters) (void)hipFree(c->counters);
     if (c->gcnt) (void)hipFree(c->gcnt);
-    if (c->world) (void)hipFree(c->world);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -581,7 +587,31 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             if (!(nodes[i].b & PBRS_LEAF_FLAG)) nodes[i].a += (uint32_t)blas_off;  // right child; the left one is i + 1
         if ((rc = upload(c, nodes.data(), nodes.size(), &S.nodes))) return rc;
         std::vector<pbrs_instance> inst(d->instances, d->instances + d->n_instances);
+        // Shading classes: one per distinct lobe signature among the materials (class 0: no lobes — emitters — and misses)
+        std::vector<uint32_t> mat_class(d->n_materials, 0u);
+        {
+            std::vector<std::string> sigs;
+            for (uint32_t m = 0; m < d->n_materials; ++m) {
+                const pbrs_material& mt = d->materials[m];
+                if (mt.n_bxdfs == 0) continue;
+                std::string sig;
+                for (uint32_t k = 0; k < mt.n_bxdfs; ++k) {
+                    const pbrs_bxdf& bx = d->bxdfs[mt.first_bxdf + k];
+                    sig += (char)('a' + bx.kind);
+                    sig += (char)('a' + (bx.kind == PBRS_BXDF_SPECULAR ? bx.intrusion : 0u));
+                    sig += (char)('a' + (bx.kind == PBRS_BXDF_DIFFUSE ? bx.oren_nayar : bx.fresnel));
+                    sig += (char)('a' + (bx.kind == PBRS_BXDF_MICROFACET && bx.alpha_x != bx.alpha_y ? 1 : 0));
+                    sig += bx.tex ? 't' : '-';
+                }
+                size_t at = 0;
+                while (at < sigs.size() && sigs[at] != sig) ++at;
+                if (at == sigs.size()) sigs.push_back(sig);
+                mat_class[m] = (uint32_t)std::min<size_t>(at + 1, PBRS_MAX_CLASSES - 1);
+            }
+            S.n_classes = (uint32_t)std::min<size_t>(sigs.size(), PBRS_MAX_CLASSES - 1);
+        }
         for (pbrs_instance& in : inst) {
+            in.pad[0] = mat_class[in.material];
             if (in.shape_kind == PBRS_SHAPE_MESH) in.blas_root += (uint32_t)blas_off;
             bool linear_identity = true;  // bit patterns: -0.0 would not do
             for (int r = 0; r < 3; ++r)
@@ -624,7 +654,6 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             for (int a = 0; a < 3; ++a) ok = ok && coord_ok(d->blas_nodes[i].min[a]) && coord_ok(d->blas_nodes[i].max[a]);
         S.fast_slab = ok ? 1u : 0u;
     }
-    S.world = c->world;
     S.refill_below = max_blas_height >= PBRS_LONG_WALK_HEIGHT ? PBRS_REFILL_BELOW_LONG : PBRS_REFILL_BELOW_SHORT;
     const uint32_t flat_feature = S.n_flat ? PBRS_FEAT_FLAT_TLAS : 0u;
     S.features = flat_feature;
@@ -692,7 +721,8 @@ int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const flo
     if (n == 0) return PBRS_OK;
     if (!origins || !dirs || !tmax) return fail(c, PBRS_E_INVALID, "null ray arrays");
     HIPCHK(c, hipSetDevice(c->device));
-    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    float4 *d_o = nullptr, *d_d = nullptr;
+    float* d_t = nullptr;
     pbrs_hit_record* d_h = nullptr;
     uint8_t* d_occ = nullptr;
     int rc = PBRS_OK;
@@ -708,13 +738,19 @@ int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const flo
             return PBRS_E_DEVICE;                                                  \
         }                                                                          \
     } while (0)
-    TRY(hipMalloc(reinterpret_cast<void**>(&d_o), (size_t)n * 12));
-    TRY(hipMalloc(reinterpret_cast<void**>(&d_d), (size_t)n * 12));
+    // rays travel as 16-byte records, the form the walks re-read their ray in (traverse.h, reload_world)
+    std::vector<float4> h_o(n), h_d(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        h_o[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.0f);
+        h_d[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], 0.0f);
+    }
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_o), (size_t)n * 16));
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_d), (size_t)n * 16));
     TRY(hipMalloc(reinterpret_cast<void**>(&d_t), (size_t)n * 4));
     if (hits_out) TRY(hipMalloc(reinterpret_cast<void**>(&d_h), (size_t)n * sizeof(pbrs_hit_record)));
     if (occluded_out) TRY(hipMalloc(reinterpret_cast<void**>(&d_occ), (size_t)n));
-    TRY(hipMemcpyAsync(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
-    TRY(hipMemcpyAsync(d_d, dirs, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemcpyAsync(d_o, h_o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemcpyAsync(d_d, h_d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     TRY(hipMemcpyAsync(d_t, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_intersect_rays, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, kPersistentBlocks)), dim3(kBlock), lds_bytes(c), c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ);
     TRY(hipGetLastError());
