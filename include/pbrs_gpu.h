@@ -13,8 +13,13 @@
  * Conventions: POD structs, little-endian, plain pointers + counts, no ownership transfer
  * (`pbrs_upload_scene` copies; the caller keeps its buffers).  Never unwinds or aborts: every call
  * returns 0 or a negative PBRS_E_* and `pbrs_last_error` explains.  The reference's error model is
- * panic; conditions that would panic there are counted in
- * `pbrs_stats.invalid_samples` and the sample proceeds with the arithmetic result.
+ * panic: where an `assert!` of the reference would fire, the device carries on with the
+ * arithmetic result, as the oracle does.  What comes of it is visible in the output and counted:
+ * `pbrs_stats.invalid_samples` is the number of camera samples whose radiance is not finite (a NaN or
+ * an infinity in any channel) — always filled, equal to the oracle's count on the same scene and
+ * seeds (tests/test_gpu_fuzz.py).  The assert sites themselves are counted by the oracle only
+ * (`oracle_stats.panics`, test infrastructure): the parity tests assert that count to be zero on the
+ * BASELINE scenes.
  * Threading: one `pbrs_ctx` per GPU; different contexts may be driven concurrently from different
  * host threads/processes; a single context is not re-entrant.
  *
@@ -239,7 +244,7 @@ typedef struct pbrs_stats {
     uint64_t tlas_nodes, blas_nodes, instances, instance_hits, triangles, tri_shading;
     uint64_t spheres, quads, cuboids, disks;
     uint64_t shadow_tlas_nodes, shadow_blas_nodes, shadow_instances, shadow_triangles, shadow_prims;
-    uint64_t invalid_samples; /* reference assert!/panic! conditions reached on device */
+    uint64_t invalid_samples; /* camera samples whose radiance has a NaN or infinite component (always filled) */
     /* HIP-event time per stage, summed over launches, in ms, on the context's stream */
     float ms_raygen, ms_extend, ms_shade, ms_shadow, ms_accumulate, ms_total;
     uint32_t launches_extend, launches_shadow, launches_shade, passes;

@@ -14,7 +14,7 @@ TRACE_MAX_BOUNCES = 16
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "closest_rays", "shadow_rays", "tlas_nodes", "blas_nodes", "instances", "instance_hits", "triangles", "spheres",
-        "quads", "cuboids", "disks", "tri_shading", "shade_events", "samples", "panics", "tlas_ties", "sphere_inside")]
+        "quads", "cuboids", "disks", "tri_shading", "shade_events", "samples", "panics", "tlas_ties", "sphere_inside", "nonfinite_samples")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

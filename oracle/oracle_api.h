@@ -19,6 +19,7 @@ typedef struct oracle_stats {
     uint64_t panics;        /* reference assert!/panic! sites reached */
     uint64_t tlas_ties;     /* tlas/src/bvh.rs:94 reached with equal t on both sides */
     uint64_t sphere_inside; /* D4: interior sphere hits (Interaction::new assert skipped) */
+    uint64_t nonfinite_samples; /* camera samples whose radiance has a NaN or infinite component (pbrs_stats.invalid_samples) */
 } oracle_stats;
 
 typedef struct oracle_hit_record {

@@ -468,6 +468,7 @@ static void copy_counters(const Counters& c, const Diag& d, oracle_stats* out) {
     out->triangles = c.triangles; out->spheres = c.spheres; out->quads = c.quads; out->cuboids = c.cuboids;
     out->disks = c.disks; out->tri_shading = c.tri_shading; out->shade_events = c.shade_events; out->samples = c.samples;
     out->panics = d.panics; out->tlas_ties = d.tlas_ties; out->sphere_inside = d.sphere_inside;
+    out->nonfinite_samples = d.nonfinite_samples;
 }
 
 // src/main.rs:192-231 restricted to the tile [x0,x0+w) x [y0,y0+h); rows are dealt to `nthreads`
@@ -511,10 +512,12 @@ int oracle_render_tile_integrator(const oracle_scene* os, uint32_t x0, uint32_t 
                     Ray ray;
                     scene.camera.shoot_ray(row, col, jx, jy, &ray);
                     REF_COUNT(samples);
-                    color_sum = color_sum + (integrator == 0   ? path_integrator(scene, ray, (int)max_depth, &rng, nullptr)
-                                             : integrator == 1 ? direct_lighting_integrator(scene, ray, (int)max_depth, &rng)
-                                             : integrator == 2 ? material_visualizer(scene, ray)
-                                                               : normal_visualizer(scene, ray, &rng));
+                    const Color li = integrator == 0   ? path_integrator(scene, ray, (int)max_depth, &rng, nullptr)
+                                     : integrator == 1 ? direct_lighting_integrator(scene, ray, (int)max_depth, &rng)
+                                     : integrator == 2 ? material_visualizer(scene, ray)
+                                                       : normal_visualizer(scene, ray, &rng);
+                    if (!(pn_isfinite(li.r) && pn_isfinite(li.g) && pn_isfinite(li.b)) && g_diag) g_diag->nonfinite_samples++;
+                    color_sum = color_sum + li;
                 }
                 Color color = color_sum * (1.0f / (float)spp);  // scale_down_by, color.rs:90-95
                 float* px = rgb_out + 3 * ((size_t)ry * w + cx);
@@ -537,6 +540,7 @@ int oracle_render_tile_integrator(const oracle_scene* os, uint32_t x0, uint32_t 
         dtotal.panics += diags[t].panics;
         dtotal.tlas_ties += diags[t].tlas_ties;
         dtotal.sphere_inside += diags[t].sphere_inside;
+        dtotal.nonfinite_samples += diags[t].nonfinite_samples;
     }
     copy_counters(total, dtotal, stats_out);
     return 0;

@@ -20,6 +20,7 @@ struct Diag {
     uint64_t panics = 0;         // would-have-panicked conditions reached
     uint64_t tlas_ties = 0;      // tlas/src/bvh.rs:94 reached with l.t == r.t
     uint64_t sphere_inside = 0;  // D4: Interaction::new assert skipped for interior sphere hits
+    uint64_t nonfinite_samples = 0;  // camera samples whose radiance is not finite
 };
 extern thread_local Diag* g_diag;
 inline void ref_panic() {

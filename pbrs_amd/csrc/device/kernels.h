@@ -868,13 +868,21 @@ __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_
 
 // ---- accumulate / finalize -----------------------------------------------------------------------------------------
 // color_sum = color_sum + integrator(...) for strictly increasing sample index (src/main.rs:205)
-__global__ void __launch_bounds__(256) k_accumulate(PathState st, float* sum, uint32_t n_pixels, uint32_t k_count) {
+// Also counts the samples whose radiance is not finite (pbrs_stats.invalid_samples): one atomic per wave that saw any.
+__global__ void __launch_bounds__(256) k_accumulate(PathState st, float* sum, uint32_t n_pixels, uint32_t k_count, unsigned long long* nonfinite) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
     f3 s = mk3(sum[p], sum[n_pixels + p], sum[2 * n_pixels + p]);
+    uint32_t bad = 0;
     for (uint32_t k = 0; k < k_count; ++k) {
         uint32_t slot = k * n_pixels + p;
-        s = s + xyz(st.L[slot]);
+        const f3 l = xyz(st.L[slot]);
+        bad += (pn_isfinite(l.x) && pn_isfinite(l.y) && pn_isfinite(l.z)) ? 0u : 1u;
+        s = s + l;
+    }
+    if (__ballot(bad != 0u)) {
+        for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(nonfinite, (unsigned long long)bad);
     }
     sum[p] = s.x;
     sum[n_pixels + p] = s.y;

@@ -55,6 +55,7 @@ struct pbrs_ctx {
     float* sum = nullptr;         // 3 * cap_pixels, planar
     float* rgb_dev = nullptr;     // 3 * cap_pixels, row-major (for the host-output variant)
     GlobalCounters* gcnt = nullptr;  // [0] extend, [1] shadow
+    unsigned long long* nonfinite = nullptr;  // samples of the current render whose radiance is not finite
 
     // timing
     std::vector<StageEvent> events;
@@ -75,6 +76,7 @@ namespace {
         hipError_t e_ = (expr);                                                                       \
         if (e_ != hipSuccess) {                                                                       \
             (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            (void)hipGetLastError(); /* reported: must not resurface in a later call's hipGetLastError() */ \
             return PBRS_E_DEVICE;                                                                     \
         }                                                                                             \
     } while (0)
@@ -133,6 +135,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         if (e != hipSuccess) {
             c->state_mem = nullptr;
             c->error = std::string("hipMalloc of the path state (") + std::to_string(total >> 20) + " MiB): " + hipGetErrorString(e);
+            (void)hipGetLastError();  // reported: must not resurface in a later call's hipGetLastError()
             return PBRS_E_DEVICE;
         }
         char* p = static_cast<char*>(c->state_mem);
@@ -237,12 +240,12 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
     uint64_t P = (uint64_t)p->w * p->h, spp = (uint64_t)p->strata_x * p->strata_y;
     uint64_t k = p->samples_per_pass;
     if (k == 0) {
-        // ~128M paths in flight (~36 GB of the 288 GB HBM for state, queues and shadow-ray records), less when that would
-        // exceed a quarter of the memory currently free.  Every bounce is a handful of launches and a persistent traversal
-        // kernel ends with the latency of its longest walks (hundreds of dependent node fetches on a deep BLAS): the
+        // ~240M paths in flight (~67 GB of the 288 GB HBM for path, hit, radiance, shadow-ray and nee records), less when
+        // that would exceed a quarter of the memory currently free.  Every bounce is a handful of launches and a persistent
+        // traversal kernel ends with the latency of its longest walks (hundreds of dependent node fetches on a deep BLAS): the
         // fewer, larger launches a frame is cut into, the less of it is spent draining (C2, 256 spp: 617 / 629 / 637
-        // Msamples/s at 32 / 64 / 128 samples per pass).
-        uint64_t target = 128ull << 20;
+        // Msamples/s at 32 / 64 / 128 samples per pass; C4: 921 / 939 at 64 / 115).  Stays under the 2^28 paths of check_params.
+        uint64_t target = 240ull << 20;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const uint64_t per_path = PBRS_STATE_BYTES_PER_PATH;  // path, hit, radiance, shadow-ray and nee records
@@ -251,6 +254,11 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
             if (fit < target) target = fit < (4ull << 20) ? (4ull << 20) : fit;
         }
         k = P >= target ? 1 : target / P;
+        if (k < 1) k = 1;
+        if (k < spp) {  // passes of equal size: 256 spp at 240 per pass is 128 + 128, not 240 + 16
+            const uint64_t passes = (spp + k - 1) / k;
+            k = (spp + passes - 1) / passes;
+        }
     }
     if (k > spp) k = spp;
     if (k < 1) k = 1;
@@ -357,7 +365,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         tm.end();
     }
     if (tm.begin(4)) return fail(c, PBRS_E_DEVICE, "event record failed");
-    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, c->sum, P, kc);
+    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, c->sum, P, kc, c->nonfinite);
     tm.end();
     HIPCHK(c, hipGetLastError());
     return PBRS_OK;
@@ -381,6 +389,7 @@ int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params*
     c->pending_times = p->time_stages != 0;
     c->pending.samples = (uint64_t)P * spp;
     if (stats) HIPCHK(c, hipMemsetAsync(c->gcnt, 0, 2 * sizeof(GlobalCounters), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->nonfinite, 0, sizeof(unsigned long long), c->stream));
     if (c->pending_times) HIPCHK(c, hipEventRecord(c->total_ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->sum, 0, 3 * (size_t)P * sizeof(float), c->stream));
     uint32_t passes = 0;
@@ -402,6 +411,11 @@ int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params*
 int collect(pbrs_ctx* c, pbrs_stats* out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     pbrs_stats s = c->pending;
+    {
+        unsigned long long bad = 0;
+        HIPCHK(c, hipMemcpy(&bad, c->nonfinite, sizeof bad, hipMemcpyDeviceToHost));
+        s.invalid_samples = bad;
+    }
     if (c->pending_counters) {
         GlobalCounters g[2];
         HIPCHK(c, hipMemcpy(g, c->gcnt, sizeof g, hipMemcpyDeviceToHost));
@@ -459,7 +473,9 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
         if (ok) c->total_ev.push_back(ev);
     }
     ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) == hipSuccess &&
-         hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) == hipSuccess;
+         hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&c->nonfinite), sizeof(unsigned long long)) == hipSuccess &&
+         hipMemset(c->nonfinite, 0, sizeof(unsigned long long)) == hipSuccess;
     if (!ok) {
         pbrs_destroy(c);
         return PBRS_E_DEVICE;
@@ -476,6 +492,7 @@ void pbrs_destroy(pbrs_ctx* c) {
     free_work(c);
     if (c->counters) (void)hipFree(c->counters);
     if (c->gcnt) (void)hipFree(c->gcnt);
+    if (c->nonfinite) (void)hipFree(c->nonfinite);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -734,6 +751,7 @@ int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const flo
         hipError_t e_ = (expr);                                                    \
         if (e_ != hipSuccess) {                                                    \
             c->error = std::string(#expr) + ": " + hipGetErrorString(e_);          \
+            (void)hipGetLastError();                                               \
             cleanup();                                                             \
             return PBRS_E_DEVICE;                                                  \
         }                                                                          \

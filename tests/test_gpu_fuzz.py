@@ -122,6 +122,7 @@ def test_random_scene_matches_oracle(gpu_ctx, seed):
             SKIPPED_FOR_TIES.append((seed, integrator))  # coincident geometry from two instances: the one documented deviation
             continue
         assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"], (seed, integrator)
+        assert st["invalid_samples"] == ost["nonfinite_samples"], (seed, integrator)  # samples whose radiance is not finite
         nan = np.isnan(ref)
         assert (nan == np.isnan(img)).all(), (seed, integrator)
         assert (img.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all(), (seed, integrator)

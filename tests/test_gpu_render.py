@@ -374,6 +374,36 @@ def test_api_errors(gpu_ctx):
     fresh.close()
 
 
+def test_failed_allocation_leaves_a_usable_context():
+    """A pass whose path state cannot be allocated fails with PBRS_E_DEVICE and leaves the context without a working set
+    (no stale capacities, no pointers into freed memory): the next, smaller render allocates afresh and is still bit-exact."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself runs on
+    sb, (w, h, sx, sy, depth) = golden_case("c2_cornell_diffuse")
+    ctx = pbrs_amd.Context(0)
+    hog = ctypes.c_void_p()
+    try:
+        ctx.upload(pbrs_amd.HostScene(sb))
+        img0, _ = ctx.render(sx, sy, depth, SEED)  # a working set exists before the failure
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        assert hip.hipMalloc(ctypes.byref(hog), ctypes.c_size_t(max(free.value - (3 << 30), 1 << 20))) == 0  # leave about 3 GiB
+        big = pbrs_amd.HostScene(scenes.build_config("c2", width=2048, height=2048)[0])
+        ctx.upload(big)
+        with pytest.raises(pbrs_amd.PbrsError, match="hipMalloc"):
+            ctx.render(8, 8, depth, SEED, samples_per_pass=60)  # 2048 x 2048 x 60 paths x ~280 B = 70 GB
+        assert hip.hipFree(hog) == 0
+        hog = ctypes.c_void_p()
+        ctx.upload(pbrs_amd.HostScene(sb))
+        img1, _ = ctx.render(sx, sy, depth, SEED)
+        assert (bits(img0) == bits(img1)).all()
+        assert (bits(img1) == bits(load_golden("c2_cornell_diffuse")["image"])).all()
+    finally:
+        if hog:
+            hip.hipFree(hog)
+        ctx.close()
+
+
 # ---- BASELINE.json full sizes: properties that need no CPU reference -------------------------------------------------------------
 
 def test_full_size_c2_properties(gpu_ctx):
