@@ -126,6 +126,9 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #ifndef PBRS_LEAN_EXTEND_WAVES  // ... and for the k_extend variants without the per-candidate shading check: 80 VGPRs, two
 #define PBRS_LEAN_EXTEND_WAVES 6  // dwords of the shared leaf step spilled — C2 extend 13.6 -> 12.8 ms per 16 spp over 5 waves
 #endif
+#ifndef PBRS_SHADOW_WAVES  // ... and for k_shadow: 76-80 VGPRs without a spill (C4 shadow 347 -> 317 ms, C3 198 -> 180 ms over 5 waves)
+#define PBRS_SHADOW_WAVES 6
+#endif
 #ifndef PBRS_SHADE_WAVES  // min waves per SIMD asked of the register allocator for k_shade (2nd arg of __launch_bounds__)
 #define PBRS_SHADE_WAVES 3
 #endif
@@ -793,7 +796,7 @@ __global__ void __launch_bounds__(256) k_class_sort(PathState st, const uint32_t
 // ---- shadow ----------------------------------------------------------------------------------------------------
 // One work item per shadow ray (persistent, same refill scheme as k_extend); writes one occlusion byte.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : PBRS_TRAV_WAVES) k_shadow(DevScene S, PathState st, const uint32_t* count, uint32_t* next,
+__global__ void __launch_bounds__(256, STATS ? 3 : PBRS_SHADOW_WAVES) k_shadow(DevScene S, PathState st, const uint32_t* count, uint32_t* next,
                                                GlobalCounters* gc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t n = count[1];  // high half of the packed (nee paths, shadow rays) counter

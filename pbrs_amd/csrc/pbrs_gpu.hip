@@ -580,8 +580,27 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         if (!(k == PBRS_SHAPE_SPHERE || k == PBRS_SHAPE_DISK || k == PBRS_SHAPE_TRIANGLE || k == PBRS_SHAPE_QUAD))
             return fail(c, PBRS_E_INVALID, "area light shape kind");
     }
-    // pending entries never exceed one sibling per level of each tree, plus the node being expanded
-    uint32_t depth = d->tlas_height + max_blas_height + 2;
+    // Depth of the per-lane stack, from the trees themselves (the heights in the description are not trusted: an entry
+    // too few would let a lane write into its neighbour's LDS).  h = levels of a tree (a lone leaf: 1).  A walk pops a node
+    // of level l with l - 1 entries pending and pushes two: at most h_tlas entries in the TLAS, h_tlas - 1 pending below an
+    // instance, and h_blas more inside it — max(h_tlas, h_tlas - 1 + h_blas) entries.  One level matters: C4's 4 + 23 levels
+    // need 26 KB per block, six blocks per CU instead of five.
+    auto tree_heights = [](const pbrs_node* nodes, uint32_t n, std::vector<uint32_t>& h) {
+        h.assign(n, 1u);  // children come after their parent (left = i + 1, right = a > i, checked above): one reverse pass
+        for (uint32_t i = n; i-- > 0;)
+            if (!(nodes[i].b & PBRS_LEAF_FLAG)) h[i] = std::max(h[i + 1], h[nodes[i].a]) + 1u;
+    };
+    for (uint32_t i = 0; i < d->n_tlas_nodes; ++i)
+        if (!(d->tlas_nodes[i].b & PBRS_LEAF_FLAG) && d->tlas_nodes[i].a <= i) return fail(c, PBRS_E_INVALID, "tlas nodes are not in pre-order");
+    for (uint32_t i = 0; i < d->n_blas_nodes; ++i)
+        if (!(d->blas_nodes[i].b & PBRS_LEAF_FLAG) && d->blas_nodes[i].a <= i) return fail(c, PBRS_E_INVALID, "blas nodes are not in pre-order");
+    std::vector<uint32_t> th, bh;
+    tree_heights(d->tlas_nodes, d->n_tlas_nodes, th);
+    tree_heights(d->blas_nodes, d->n_blas_nodes, bh);
+    const uint32_t tlas_levels = th[0];
+    max_blas_height = 0;
+    for (uint32_t i = 0; i < d->n_meshes; ++i) max_blas_height = std::max(max_blas_height, bh[d->meshes[i].root]);
+    uint32_t depth = std::max(tlas_levels, tlas_levels - 1u + max_blas_height);
     if ((size_t)depth * kBlock * sizeof(uint32_t) > kLdsBytesPerCU / 2) return fail(c, PBRS_E_LIMIT, "traversal stack exceeds the LDS budget");
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
