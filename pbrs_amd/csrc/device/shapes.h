@@ -62,7 +62,16 @@ struct DevScene {
 #define PBRS_FEAT_FLAT_TLAS 4u      // the leaf copies at DevScene::flat_off are built: rays on the division-free box test scan the TLAS leaves
 #define PBRS_FEAT_ALL 7u
 #define PBRS_FLAT_TLAS_MIN 2u
-#define PBRS_FLAT_TLAS_MAX 16u
+// Largest TLAS the wave scans instead of walking (tools/tlas_probe.py, C5's scene family at 960x540, ms per 64 spp, walk vs
+// scan): closest hit 4.84 / 4.74 at 20 instances, 5.10 / 5.28 at 24, 5.66 / 6.15 at 30 — the scan only filters there and every
+// surviving leaf is still visited; any hit 3.33 / 2.38 at 20, 3.58 / 2.53 at 24, 3.97 / 2.86 at 30 — there the scan is the test.
+// The candidate mask is one word: <= 32.
+#ifndef PBRS_FLAT_TLAS_MAX
+#define PBRS_FLAT_TLAS_MAX 20u         // k_extend
+#endif
+#ifndef PBRS_FLAT_TLAS_MAX_ANYHIT
+#define PBRS_FLAT_TLAS_MAX_ANYHIT 32u  // k_shadow
+#endif
 
 // Per-lane work counters (instrumented kernel variant only; SURVEY.md §8(d) units).
 struct WorkCounters {

@@ -201,7 +201,7 @@ struct FlatScan {
     }
     // Returns, to each fresh lane, the mask of the leaves whose box its ray R (on the division-free test) passes within
     // t_max; `tested` counts the box tests this lane ran as a helper.  Every lane of the wave calls this together;
-    // S.n_flat <= PBRS_FLAT_TLAS_MAX = 16.
+    // S.n_flat <= PBRS_FLAT_TLAS_MAX_ANYHIT = 32.
     PD static uint32_t run(const DevScene& S, bool fresh, const RaySpace& R, float t_max, uint32_t& tested) {
         const uint64_t m = __ballot(fresh);
         if (m == 0) return 0u;

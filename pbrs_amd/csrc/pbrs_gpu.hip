@@ -64,6 +64,7 @@ struct pbrs_ctx {
     pbrs_stats pending{};
     bool pending_counters = false, pending_times = false;
     bool textured = false;  // the uploaded scene evaluates non-Solid textures: k_shade<.., true>
+    bool shadow_flat = false;      // k_shadow scans the TLAS leaves (up to PBRS_FLAT_TLAS_MAX_ANYHIT instances; k_extend: S.features)
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
     bool sort_classes = true;      // PBRS_SORT_CLASSES=0 in the environment turns the class sort off (A/B timing)
     uint64_t pending_closest = 0;
@@ -268,8 +269,12 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
 // The traversal kernels are instantiated per scene-feature set (device/shapes.h PBRS_FEAT_*); the instrumented variant
 // exists for the full set only.  k_shadow never evaluates shading frames, so only PBRS_FEAT_ANALYTIC selects it.
 void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* heads) {
+    // k_extend scans the TLAS leaves only up to PBRS_FLAT_TLAS_MAX instances (S.features); the leaf copies may exist for
+    // k_shadow alone, and the instrumented variant, which carries every feature, must then walk the tree like the timed one
+    DevScene S = c->S;
+    if (!(S.features & PBRS_FEAT_FLAT_TLAS)) S.n_flat = 0u;
 #define PBRS_LAUNCH_EXTEND(ST, F) \
-    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, set, count, n_direct, heads, c->gcnt)
+    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt)
     if (stats) {
         PBRS_LAUNCH_EXTEND(true, PBRS_FEAT_ALL);
         return;
@@ -294,7 +299,7 @@ void launch_shadow(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uin
         PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS);
         return;
     }
-    switch (c->S.features & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS)) {
+    switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->shadow_flat ? PBRS_FEAT_FLAT_TLAS : 0u)) {
         case 0u: PBRS_LAUNCH_SHADOW(false, 0u); break;
         case PBRS_FEAT_ANALYTIC: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC); break;
         case PBRS_FEAT_FLAT_TLAS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_FLAT_TLAS); break;
@@ -609,7 +614,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     {
         // DevScene::nodes: the TLAS, then its leaves alone in pre-order when the TLAS is small (the shared scan), then every
         // BLAS, in one array with absolute links — a walk reads nodes + index whatever tree it is in.
-        const bool scan = d->n_instances >= PBRS_FLAT_TLAS_MIN && d->n_instances <= PBRS_FLAT_TLAS_MAX;
+        const bool scan = d->n_instances >= PBRS_FLAT_TLAS_MIN && d->n_instances <= PBRS_FLAT_TLAS_MAX_ANYHIT;
         std::vector<pbrs_node> nodes(d->tlas_nodes, d->tlas_nodes + d->n_tlas_nodes);
         S.flat_off = (uint32_t)nodes.size();
         if (scan)
@@ -691,7 +696,9 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         S.fast_slab = ok ? 1u : 0u;
     }
     S.refill_below = max_blas_height >= PBRS_LONG_WALK_HEIGHT ? PBRS_REFILL_BELOW_LONG : PBRS_REFILL_BELOW_SHORT;
-    const uint32_t flat_feature = S.n_flat ? PBRS_FEAT_FLAT_TLAS : 0u;
+    // the leaf copies serve k_shadow up to PBRS_FLAT_TLAS_MAX_ANYHIT instances, k_extend up to PBRS_FLAT_TLAS_MAX
+    c->shadow_flat = S.n_flat != 0u;
+    const uint32_t flat_feature = (S.n_flat != 0u && d->n_instances <= PBRS_FLAT_TLAS_MAX) ? PBRS_FEAT_FLAT_TLAS : 0u;
     S.features = flat_feature;
     for (uint32_t i = 0; i < d->n_instances; ++i) {
         const pbrs_instance& in = d->instances[i];

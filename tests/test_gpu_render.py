@@ -33,7 +33,7 @@ def test_image_matches_golden_and_counters(gpu_ctx, name):
     assert st["closest_rays"] == want["closest_rays"] and st["shadow_rays"] == want["shadow_rays"]
     assert st["shade_events"] == want["shade_events"] and st["samples"] == want["samples"]
     hs = pbrs_amd.HostScene(sb)
-    if not 2 <= hs.desc.n_instances <= 16:
+    if not 2 <= hs.desc.n_instances <= 32:
         assert st["tlas_nodes"] + st["shadow_tlas_nodes"] == want["tlas_nodes"]
     else:
         # a TLAS of 2..16 instances is not walked: the wave tests every leaf box for each new ray (FlatScan, rays on the
@@ -154,6 +154,21 @@ def _parallel_quad_scene(textured):
     sb.env = (0.2, 0.25, 0.3)
     sb.set_camera(80, 56, deg(50.0), (0.2, 2.2, -6.0), (0, 1.0, 0.8))
     return sb
+
+
+@pytest.mark.parametrize("n_objects,n_lights", [(9, 9), (10, 9), (15, 15), (16, 15)])
+def test_scan_limits_of_the_two_traversal_kernels(gpu_ctx, n_objects, n_lights):
+    """C5's scene family at 20, 21, 32 and 33 instances: k_extend scans the TLAS leaves up to 20 instances, k_shadow up to 32,
+    beyond that each walks the tree — the image is the oracle's at every size."""
+    sb = scenes.many_lights_scene(width=72, height=40, n_objects=n_objects, n_lights=n_lights)
+    hs = pbrs_amd.HostScene(sb)
+    assert hs.desc.n_instances == n_objects + n_lights + 2
+    gpu_ctx.upload(hs)
+    img, st = gpu_ctx.render(2, 2, 8, 5, counters=True)
+    ref, ost = OracleScene(sb).render(2, 2, 8, 5)
+    assert ost["tlas_ties"] == 0
+    assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert (bits(img) == bits(ref)).all()
 
 
 @pytest.mark.parametrize("textured", [False, True])

@@ -132,11 +132,12 @@ def test_leaf_with_many_triangles(gpu_ctx):
     assert st_gpu["blas_nodes"] + st_gpu["shadow_blas_nodes"] == st_ref["blas_nodes"]
 
 
-@pytest.mark.parametrize("n_inst", [1, 2, 3, 7, 15, 16, 17, 40])
+@pytest.mark.parametrize("n_inst", [1, 2, 3, 7, 15, 16, 17, 20, 21, 31, 32, 33, 40])
 def test_tlas_sizes_around_the_shared_scan(gpu_ctx, n_inst):
-    """TLAS of 2..16 instances: the wave tests every leaf box for its new rays (FlatScan: ceil(n / 2) helper slots per ray,
-    two leaves per slot); outside that range, and for rays off the division-free box test, the tree is walked.  Same
-    geometry recipe at every size: spheres, cuboids, quads and two-triangle meshes on a ring, some overlapping."""
+    """TLAS of 2..32 instances: the wave tests every leaf box for its new rays (FlatScan: ceil(n / 2) helper slots per ray,
+    two leaves per slot; the pipeline's k_extend up to 20 instances, k_shadow and this harness up to 32); outside that
+    range, and for rays off the division-free box test, the tree is walked.  Same geometry recipe at every size: spheres,
+    cuboids, quads and two-triangle meshes on a ring, some overlapping."""
     from pbrs_amd.spec import SceneBuilder, Transform, deg
     sb = SceneBuilder()
     m = sb.lambertian((0.5, 0.5, 0.5))
