@@ -371,7 +371,15 @@ PD pbrs_tri_verts load_tri(const pbrs_tri_verts* p) {
 }
 // intersect_triangle / intersect_triangle_pred (simple.rs:435-495) with `(p0-p1).cross(p2-p1).try_hat()`
 // taken from the flattened triangle (host-evaluated with the same operand order; NaN = try_hat was None).
-PD bool mesh_tri_hit(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max, TriHit& h) {
+//
+// BARY = false (the closest-hit kernels that pass on t only: k_shade recomputes the winner's barycentrics): the three
+// normalising divisions and the `hit_pos` NaN test (simple.rs:462-469, Q22) are skipped where their outcome is known.
+// Past the sign test b0, b1, b2 are non-NaN and of one sign, so |b_i| <= |b0 + b1 + b2|: if that sum is finite and not
+// zero the quotients lie in [0, 1], and with vertex coordinates of moderate size (`coords_ok`: DevScene::fast_slab, every
+// BLAS box and hence every vertex within 2^40) `barycentric_lerp` of them is finite — the hit stands.  A zero or
+// non-finite sum takes the literal path.
+template <bool BARY>
+PD bool mesh_tri_hit_t(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max, bool coords_ok, TriHit& h) {
     if (tv.nx != tv.nx) return false;
     f3 p0 = ld3(tv.p0), p1 = ld3(tv.p1), p2 = ld3(tv.p2);
     f3 normal = facing(mk3(tv.nx, tv.ny, tv.nz), d);
@@ -385,18 +393,21 @@ PD bool mesh_tri_hit(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max, TriHit& 
     bool s0 = b0 > 0.0f, s1 = b1 > 0.0f, s2 = b2 > 0.0f;
     if (!((s0 && s1 && s2) || (!s0 && !s1 && !s2))) return false;
     float total_area = b0 + b1 + b2;
+    h.t = t;
+    h.normal = normal;
+    h.b0 = h.b1 = h.b2 = 0.0f;
+    if (!BARY && coords_ok && pn_isfinite(total_area) && total_area != 0.0f) return true;
     b0 = b0 / total_area;
     b1 = b1 / total_area;
     b2 = b2 / total_area;
     f3 hit_pos = bary_lerp(p0, p1, p2, b0, b1);
     if (has_nan3(hit_pos)) return false;
-    h.t = t;
     h.b0 = b0;
     h.b1 = b1;
     h.b2 = b2;
-    h.normal = normal;
     return true;
 }
+PD bool mesh_tri_hit(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max, TriHit& h) { return mesh_tri_hit_t<true>(tv, o, d, t_max, false, h); }
 PD bool mesh_tri_pred(const pbrs_tri_verts& tv, f3 o, f3 d, float t_max) {
     if (tv.nx != tv.nx) return false;
     f3 p0 = ld3(tv.p0), p1 = ld3(tv.p1), p2 = ld3(tv.p2);

@@ -462,7 +462,10 @@ struct ClosestWalk {
             pbrs_tri_verts tv = load_tri(S.tv + hti);
             CNT(triangles);
             TriHit h;
-            bool hit = mesh_tri_hit(tv, ho, hd, hlt, h);
+            // the barycentrics leave the walk only through the shading check, the counters' variant and the parity harness
+            // (all FEAT_ALL / STATS); the lean pipeline kernels pass on t, instance and primitive
+            constexpr bool need_bary = STATS || (FEAT & PBRS_FEAT_SHADING_CHECK) != 0u;
+            bool hit = mesh_tri_hit_t<need_bary>(tv, ho, hd, hlt, S.fast_slab != 0u, h);
             if (hit && (hinfo & 7u) == PBRS_SHAPE_MESH) CNT(tri_shading);
             // The reference builds the shading frame of every geometric hit (blas.rs:166-206) and drops the hit when
             // the tangent check fails (Q22).  Only a hit that would replace outer_hit can change the result (hmt is
