@@ -117,6 +117,9 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #define PBRS_REFILL_BELOW_LONG 48u   // C4 extend 25.9 / 24.5 / 23.8 ms per 16 spp at 24 / 40 / 48
 #endif
 #define PBRS_LONG_WALK_HEIGHT 12u    // a mesh whose BLAS is at least this high makes the scene's walks "long"
+#ifndef PBRS_NODE_STEPS_LONG
+#define PBRS_NODE_STEPS_LONG 3u
+#endif
 #ifndef PBRS_CHUNK_MAX
 #define PBRS_CHUNK_MAX 512u
 #endif
@@ -152,7 +155,17 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #ifndef PBRS_SHD_LEAF_MIN
 #define PBRS_SHD_LEAF_MIN 8
 #endif
-#define PBRS_STEP_WALK(walk, S, stk, cnt, XFER_MIN, LEAF_MIN)                                                  \
+// Scenes with long walks (a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: PBRS_FEAT_LONG_WALKS) take PBRS_NODE_STEPS_LONG
+// node steps per loop round: most rounds of a deep walk are node steps, and the checks around them (who waits at a
+// boundary, who holds a leaf, who is done) then run a third as often.  C4 (23 levels), ms per frame extend / shadow at
+// 1 / 2 / 3 / 4 / 6 steps: 562 / 530 / 523 / 523 / 537 and 321 / 301 / 295 / 295 / 301; short walks lose (two steps: C2 -2 %,
+// C3 -1 %: the later steps run at few lanes) and keep one.
+#define PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS)                            \
+    do {                                                                           \
+        _Pragma("unroll") for (uint32_t k_ = 1; k_ < (NSTEPS); ++k_)               \
+            if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);          \
+    } while (0)
+#define PBRS_STEP_WALK(walk, S, stk, cnt, XFER_MIN, LEAF_MIN, NSTEPS)                                                  \
     do {                                                                                                       \
         const uint32_t nx = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_XFER));                         \
         if (nx) {                                                                                              \
@@ -163,6 +176,7 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
         }                                                                                                      \
         PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                                      \
         if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                                          \
+        PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS);                                                              \
         const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                         \
         if (nl && (nl >= LEAF_MIN || __ballot(walk.mode == PBRS_WALK_NODE) == 0)) {                            \
             PBRS_PROBE_LEAF_COUNT(cnt);                                                                        \
@@ -277,7 +291,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
-    ClosestWalk<STATS, FEAT> walk;
+    ClosestWalk<STATS, (FEAT & PBRS_FEAT_ALL)> walk;
     walk.mode = PBRS_WALK_IDLE;
     uint32_t item = 0;  // queue position of the lane's ray
     WaveWork work = wave_work_init(n);
@@ -308,7 +322,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
             }
             if (live == 0) break;
         }
-        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN);
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN, (FEAT & PBRS_FEAT_LONG_WALKS) ? PBRS_NODE_STEPS_LONG : 1u);
     }
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
 }
@@ -804,7 +818,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_SHADOW_WAVES) k_shadow(D
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
-    AnyWalk<STATS, FEAT> walk;
+    AnyWalk<STATS, (FEAT & PBRS_FEAT_ALL)> walk;
     walk.mode = PBRS_WALK_IDLE;
     uint32_t item = 0, rec = 0;
     WaveWork work = wave_work_init(n);
@@ -843,7 +857,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_SHADOW_WAVES) k_shadow(D
             }
             if (live == 0) break;
         }
-        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN);
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN, (FEAT & PBRS_FEAT_LONG_WALKS) ? PBRS_NODE_STEPS_LONG : 1u);
     }
     flush_counters<STATS>(cnt, gc, true, nrays, 0u);
 }

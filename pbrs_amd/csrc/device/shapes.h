@@ -61,6 +61,7 @@ struct DevScene {
 #define PBRS_FEAT_SHADING_CHECK 2u  // some mesh needs the tangent check of blas.rs:193-200 evaluated per candidate hit
 #define PBRS_FEAT_FLAT_TLAS 4u      // the leaf copies at DevScene::flat_off are built: rays on the division-free box test scan the TLAS leaves
 #define PBRS_FEAT_ALL 7u
+#define PBRS_FEAT_LONG_WALKS 8u     // kernels only (not a property of the walks): several node steps per loop round (kernels.h)
 #define PBRS_FLAT_TLAS_MIN 2u
 // Largest TLAS the wave scans instead of walking (tools/tlas_probe.py, C5's scene family at 960x540, ms per 64 spp, walk vs
 // scan): closest hit 4.84 / 4.74 at 20 instances, 5.10 / 5.28 at 24, 5.66 / 6.15 at 30 — the scan only filters there and every

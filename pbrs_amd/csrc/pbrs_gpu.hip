@@ -64,6 +64,7 @@ struct pbrs_ctx {
     pbrs_stats pending{};
     bool pending_counters = false, pending_times = false;
     bool textured = false;  // the uploaded scene evaluates non-Solid textures: k_shade<.., true>
+    bool long_walks = false;       // a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: the PBRS_FEAT_LONG_WALKS kernels
     bool shadow_flat = false;      // k_shadow scans the TLAS leaves (up to PBRS_FLAT_TLAS_MAX_ANYHIT instances; k_extend: S.features)
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
     bool sort_classes = true;      // PBRS_SORT_CLASSES=0 in the environment turns the class sort off (A/B timing)
@@ -279,7 +280,7 @@ void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, uint32_t 
         PBRS_LAUNCH_EXTEND(true, PBRS_FEAT_ALL);
         return;
     }
-    switch (c->S.features & PBRS_FEAT_ALL) {
+    switch ((c->S.features & PBRS_FEAT_ALL) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
         case 0u: PBRS_LAUNCH_EXTEND(false, 0u); break;
         case 1u: PBRS_LAUNCH_EXTEND(false, 1u); break;
         case 2u: PBRS_LAUNCH_EXTEND(false, 2u); break;
@@ -287,7 +288,15 @@ void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, uint32_t 
         case 4u: PBRS_LAUNCH_EXTEND(false, 4u); break;
         case 5u: PBRS_LAUNCH_EXTEND(false, 5u); break;
         case 6u: PBRS_LAUNCH_EXTEND(false, 6u); break;
-        default: PBRS_LAUNCH_EXTEND(false, 7u); break;
+        case 7u: PBRS_LAUNCH_EXTEND(false, 7u); break;
+        case 8u: PBRS_LAUNCH_EXTEND(false, 8u); break;
+        case 9u: PBRS_LAUNCH_EXTEND(false, 9u); break;
+        case 10u: PBRS_LAUNCH_EXTEND(false, 10u); break;
+        case 11u: PBRS_LAUNCH_EXTEND(false, 11u); break;
+        case 12u: PBRS_LAUNCH_EXTEND(false, 12u); break;
+        case 13u: PBRS_LAUNCH_EXTEND(false, 13u); break;
+        case 14u: PBRS_LAUNCH_EXTEND(false, 14u); break;
+        default: PBRS_LAUNCH_EXTEND(false, 15u); break;
     }
 #undef PBRS_LAUNCH_EXTEND
 }
@@ -299,11 +308,15 @@ void launch_shadow(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uin
         PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS);
         return;
     }
-    switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->shadow_flat ? PBRS_FEAT_FLAT_TLAS : 0u)) {
+    switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->shadow_flat ? PBRS_FEAT_FLAT_TLAS : 0u) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
         case 0u: PBRS_LAUNCH_SHADOW(false, 0u); break;
         case PBRS_FEAT_ANALYTIC: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC); break;
         case PBRS_FEAT_FLAT_TLAS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_FLAT_TLAS); break;
-        default: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS); break;
+        case PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS); break;
+        case PBRS_FEAT_LONG_WALKS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_LONG_WALKS); break;
+        case PBRS_FEAT_LONG_WALKS | PBRS_FEAT_ANALYTIC: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_LONG_WALKS | PBRS_FEAT_ANALYTIC); break;
+        case PBRS_FEAT_LONG_WALKS | PBRS_FEAT_FLAT_TLAS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_LONG_WALKS | PBRS_FEAT_FLAT_TLAS); break;
+        default: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_LONG_WALKS | PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS); break;
     }
 #undef PBRS_LAUNCH_SHADOW
 }
@@ -696,6 +709,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         S.fast_slab = ok ? 1u : 0u;
     }
     S.refill_below = max_blas_height >= PBRS_LONG_WALK_HEIGHT ? PBRS_REFILL_BELOW_LONG : PBRS_REFILL_BELOW_SHORT;
+    c->long_walks = max_blas_height >= PBRS_LONG_WALK_HEIGHT;
     // the leaf copies serve k_shadow up to PBRS_FLAT_TLAS_MAX_ANYHIT instances, k_extend up to PBRS_FLAT_TLAS_MAX
     c->shadow_flat = S.n_flat != 0u;
     const uint32_t flat_feature = (S.n_flat != 0u && d->n_instances <= PBRS_FLAT_TLAS_MAX) ? PBRS_FEAT_FLAT_TLAS : 0u;
@@ -714,16 +728,17 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     c->stack_depth = depth;
     c->has_scene = true;
     size_t lds = lds_bytes(c);
+#define PBRS_K(expr) reinterpret_cast<const void*>(&expr)
     const void* traversal_kernels[] = {
-        reinterpret_cast<const void*>(&k_extend<false, 0u>), reinterpret_cast<const void*>(&k_extend<false, 1u>),
-        reinterpret_cast<const void*>(&k_extend<false, 2u>), reinterpret_cast<const void*>(&k_extend<false, 3u>),
-        reinterpret_cast<const void*>(&k_extend<false, 4u>), reinterpret_cast<const void*>(&k_extend<false, 5u>),
-        reinterpret_cast<const void*>(&k_extend<false, 6u>), reinterpret_cast<const void*>(&k_extend<false, 7u>),
-        reinterpret_cast<const void*>(&k_extend<true, PBRS_FEAT_ALL>),
-        reinterpret_cast<const void*>(&k_shadow<false, 0u>), reinterpret_cast<const void*>(&k_shadow<false, PBRS_FEAT_ANALYTIC>),
-        reinterpret_cast<const void*>(&k_shadow<false, PBRS_FEAT_FLAT_TLAS>),
-        reinterpret_cast<const void*>(&k_shadow<false, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>),
-        reinterpret_cast<const void*>(&k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>)};
+        PBRS_K((k_extend<false, 0u>)),  PBRS_K((k_extend<false, 1u>)),  PBRS_K((k_extend<false, 2u>)),  PBRS_K((k_extend<false, 3u>)),
+        PBRS_K((k_extend<false, 4u>)),  PBRS_K((k_extend<false, 5u>)),  PBRS_K((k_extend<false, 6u>)),  PBRS_K((k_extend<false, 7u>)),
+        PBRS_K((k_extend<false, 8u>)),  PBRS_K((k_extend<false, 9u>)),  PBRS_K((k_extend<false, 10u>)), PBRS_K((k_extend<false, 11u>)),
+        PBRS_K((k_extend<false, 12u>)), PBRS_K((k_extend<false, 13u>)), PBRS_K((k_extend<false, 14u>)), PBRS_K((k_extend<false, 15u>)),
+        PBRS_K((k_extend<true, PBRS_FEAT_ALL>)),
+        PBRS_K((k_shadow<false, 0u>)), PBRS_K((k_shadow<false, 1u>)), PBRS_K((k_shadow<false, 4u>)), PBRS_K((k_shadow<false, 5u>)),
+        PBRS_K((k_shadow<false, 8u>)), PBRS_K((k_shadow<false, 9u>)), PBRS_K((k_shadow<false, 12u>)), PBRS_K((k_shadow<false, 13u>)),
+        PBRS_K((k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>))};
+#undef PBRS_K
     for (const void* k : traversal_kernels) HIPCHK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect_rays), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return PBRS_OK;
