@@ -270,7 +270,7 @@ struct ClosestWalk {
         best.b1 = best.b2 = 0.0f;
         in_blas = false;
         t_max = tmax;
-        lt = 0.0f;
+        lt = tmax;  // lt is the extent of the tree the lane is in: t_max in the TLAS, the cloned ray's inside a mesh
         mt = pn_inf();
         mprim = cur_inst = inst_info = leaf_a = leaf_end = 0;
         mb1 = mb2 = 0.0f;
@@ -325,7 +325,7 @@ struct ClosestWalk {
             }
         }
         const pbrs_node node = load_node(S.nodes + ni);
-        if (!slab_rs(node, C, in_blas ? lt : t_max)) {
+        if (!slab_rs(node, C, lt)) {
             if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = PBRS_WALK_XFER;
             return;
         }
@@ -370,6 +370,7 @@ struct ClosestWalk {
                     t_max = mt;
                 }
             }
+            lt = t_max;  // back in the TLAS
             return;
         }
         // Instance::intersect (instance.rs:50-67): the ray goes into the instance's space and stays there until the
