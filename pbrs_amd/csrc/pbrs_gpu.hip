@@ -709,7 +709,10 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         S.fast_slab = ok ? 1u : 0u;
     }
     S.refill_below = max_blas_height >= PBRS_LONG_WALK_HEIGHT ? PBRS_REFILL_BELOW_LONG : PBRS_REFILL_BELOW_SHORT;
-    c->long_walks = max_blas_height >= PBRS_LONG_WALK_HEIGHT;
+    if (const char* e = getenv("PBRS_REFILL_BELOW")) S.refill_below = (uint32_t)std::atoi(e);  // developer override (A/B timing)
+    // long walks: the levels a ray actually walks — the deepest BLAS, plus the TLAS where it is not scanned
+    c->long_walks = (S.n_flat ? 0u : tlas_levels) + max_blas_height >= PBRS_LONG_WALK_HEIGHT;
+    if (const char* e = getenv("PBRS_LONG_WALKS")) c->long_walks = std::atoi(e) != 0;  // developer override (A/B timing)
     // the leaf copies serve k_shadow up to PBRS_FLAT_TLAS_MAX_ANYHIT instances, k_extend up to PBRS_FLAT_TLAS_MAX
     c->shadow_flat = S.n_flat != 0u;
     const uint32_t flat_feature = (S.n_flat != 0u && d->n_instances <= PBRS_FLAT_TLAS_MAX) ? PBRS_FEAT_FLAT_TLAS : 0u;
