@@ -197,6 +197,9 @@ class Workload:
             with open(tpath) as f:
                 traffic_doc = json.load(f)
             traffic_src = os.path.relpath(tpath, ROOT)
+            # per-launch figures only carry over when a launch is the same size: same number of passes per frame
+            if traffic_doc.get("geometry", {}).get("passes") not in (None, cst["passes"]):
+                traffic_doc, traffic_src = None, f"{traffic_src} ignored: measured at {traffic_doc['geometry']['passes']} passes per frame, this run has {cst['passes']}"
         rep = roofline.stage_report(cst, times, scene_nbytes=self.hs.nbytes, traffic_doc=traffic_doc)
         dom_name, dom = roofline.dominant(rep)
         trav = roofline.traversal(rep)
