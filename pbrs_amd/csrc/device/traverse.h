@@ -71,6 +71,19 @@ PD RaySpace reload_world(const DevScene& S, LaneStack stk) {
     const float4 a = stk.ro[stk.item], b = stk.rd[stk.item];
     return make_space(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), S.fast_slab != 0);
 }
+// What enter_instance did to the lane's space, for the way back out
+#define PBRS_SPACE_WORLD 0u       // nothing: the instance is the identity
+#define PBRS_SPACE_MOVED 1u       // origin, direction and reciprocals are the instance's: reload_world
+#define PBRS_SPACE_TRANSLATED 2u  // only the origin moved and the ray stayed on the division-free test: the world ray is
+                                  // the same direction, the same reciprocals and the origin of the ray record
+PD void leave_instance(const DevScene& S, LaneStack stk, uint32_t moved, RaySpace& C) {
+    if (moved == PBRS_SPACE_TRANSLATED && C.fast) {
+        const float4 a = stk.ro[stk.item];
+        C.o = mk3(a.x, a.y, a.z);  // in range: the walk started on the division-free test with it
+    } else if (moved != PBRS_SPACE_WORLD) {
+        C = reload_world(S, stk);
+    }
+}
 PD float qdiv(float n, double r) { return (float)((double)n * r); }
 // geometry/src/bvh.rs:84-99 (same min/max/NaN conventions as dmath.h::slab_test)
 PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
@@ -91,9 +104,9 @@ PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
 // bit-exactly the identity the Mat4 products return the operand's own bits as long as every component
 // is finite and non-zero (1*x + 0*y + 0*z + 0*w = x exactly), which is what W.fast plus a non-zero
 // origin guarantee; anything else takes the literal products.
-// Returns false when the lane's ray is unchanged (C still is the world ray).
-PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, bool need_slab, LaneStack stk) {
-    if ((in.flags & PBRS_INSTANCE_IDENTITY) && C.fast && C.o.x != 0.0f && C.o.y != 0.0f && C.o.z != 0.0f) return false;
+// Returns PBRS_SPACE_*: what became of the lane's space.
+PD uint32_t enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, bool need_slab, LaneStack stk) {
+    if ((in.flags & PBRS_INSTANCE_IDENTITY) && C.fast && C.o.x != 0.0f && C.o.y != 0.0f && C.o.z != 0.0f) return PBRS_SPACE_WORLD;
     f3 oo = xf_apply(in.inv, C.o, 1.0f);
     // A pure translation (the 3x3 part of `inverse` bit-exactly the identity, flagged at upload): the Mat4 product
     // returns the direction's own bits — 1*x + 0*y + 0*z + t*0 with x finite and non-zero, which C.fast guarantees — so
@@ -104,7 +117,7 @@ PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, 
             C.fast = false;
             C.rx = C.ry = C.rz = 0.0;
         }
-        return true;
+        return PBRS_SPACE_TRANSLATED;
     }
     f3 od = xf_apply(in.inv, C.d, 0.0f);
     if (need_slab) {
@@ -114,7 +127,7 @@ PD bool enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, 
         C.d = od;
         C.fast = false;
     }
-    return true;
+    return PBRS_SPACE_MOVED;
 }
 
 // Closest hit, as a resumable walk (one lane = one ray; the kernel interleaves many walks per lane, see
@@ -254,11 +267,12 @@ struct ClosestWalk {
     Hit best;       // best.t stays +inf until the first candidate: `!(best.t < t)` then accepts it, as Option::None does
     float t_max, lt, mt, mb1, mb2;  // lt: the cloned ray's t_max inside intersect_bvh; mt: outer_hit.ray_t
     uint32_t mprim, cur_inst;
-    uint32_t inst_info;  // of the instance the lane is in: shape kind | mesh flags << 3 | bit 31: an analytic candidate is held
+    uint32_t inst_info;  // of the instance the lane is in: shape kind | mesh flags << 3 | bit 30: entered by translating the origin only
+                         // | bit 31: an analytic candidate is held
     uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or leaf_a = the analytic shape
     int sp, blas_base;
     uint32_t cand;        // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
-    bool in_blas, moved;  // moved: C is not the world ray
+    bool in_blas, moved;  // moved: C is not the world ray (inst_info bit 30: only its origin differs)
     uint32_t mode;
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
@@ -356,7 +370,7 @@ struct ClosestWalk {
         mode = PBRS_WALK_NODE;
         if (in_blas) {  // intersect_bvh / the shape returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
             in_blas = false;
-            if (moved) C = reload_world(S, stk);
+            leave_instance(S, stk, !moved ? PBRS_SPACE_WORLD : (inst_info & 0x40000000u) ? PBRS_SPACE_TRANSLATED : PBRS_SPACE_MOVED, C);
             // a mesh candidate always has t < inf (it beat outer_hit.ray_t = inf); an analytic one may sit at t == +inf
             // (x / 0 with an infinite extent), so those are flagged
             if (mt < pn_inf() || (inst_info & 0x80000000u)) {
@@ -379,13 +393,14 @@ struct ClosestWalk {
         const pbrs_instance& in = S.inst[cur_inst];
         CNT(instances);
         const uint32_t kind = inst_info;
-        moved = enter_instance(S, in, C, kind == PBRS_SHAPE_MESH, stk);
+        const uint32_t space = enter_instance(S, in, C, kind == PBRS_SHAPE_MESH, stk);
+        moved = space != PBRS_SPACE_WORLD;
         in_blas = true;
         blas_base = sp;
         lt = t_max;
         mt = pn_inf();
         if (kind == PBRS_SHAPE_MESH) {
-            inst_info = kind | (in.mesh_flags << 3);
+            inst_info = kind | (in.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
             stk.put(sp++, in.blas_root);
         } else if (kind == PBRS_SHAPE_TRIANGLE) {
             // IsolatedTriangle (simple.rs:417-426): one triangle record, no boxes, no shading frame
@@ -525,7 +540,7 @@ struct AnyWalk {
     uint32_t leaf_a, leaf_end, inst_kind;
     int sp, blas_base;
     uint32_t cand;  // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
-    bool in_blas, occluded, moved;
+    bool in_blas, occluded, moved;  // moved: C is not the world ray (inst_kind bit 8: only its origin differs)
     uint32_t mode;
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
@@ -606,15 +621,17 @@ struct AnyWalk {
         mode = PBRS_WALK_NODE;
         if (in_blas) {
             in_blas = false;
-            if (moved) C = reload_world(S, stk);
+            leave_instance(S, stk, !moved ? PBRS_SPACE_WORLD : (inst_kind & 0x100u) ? PBRS_SPACE_TRANSLATED : PBRS_SPACE_MOVED, C);
             return;
         }
         const pbrs_instance& in = S.inst[leaf_a];
         CNT(instances);
-        moved = enter_instance(S, in, C, inst_kind == PBRS_SHAPE_MESH, stk);
+        const uint32_t space = enter_instance(S, in, C, inst_kind == PBRS_SHAPE_MESH, stk);
+        moved = space != PBRS_SPACE_WORLD;
         in_blas = true;
         blas_base = sp;
         if (inst_kind == PBRS_SHAPE_MESH) {
+            if (space == PBRS_SPACE_TRANSLATED) inst_kind |= 0x100u;  // only meshes: the tests below read the kind before or mask it
             stk.put(sp++, in.blas_root);
         } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {  // IsolatedTriangle::occludes (simple.rs:428-433): its triangle record
             leaf_a = in.blas_root;
@@ -629,7 +646,7 @@ struct AnyWalk {
     // `intersect_bvh_pred` stops at a leaf's first occluder (blas.rs:478-495): the owner counts its triangles up to that one.
     PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
         const bool tri_leaf = mode == PBRS_WALK_LEAF &&
-                              (!(FEAT & PBRS_FEAT_ANALYTIC) || inst_kind == PBRS_SHAPE_MESH || inst_kind == PBRS_SHAPE_TRIANGLE);
+                              (!(FEAT & PBRS_FEAT_ANALYTIC) || (inst_kind & 7u) == PBRS_SHAPE_MESH || inst_kind == PBRS_SHAPE_TRIANGLE);
         if ((FEAT & PBRS_FEAT_ANALYTIC) && mode == PBRS_WALK_LEAF && !tri_leaf) analytic_leaf(S, cnt);
         TriShare sh;
         sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
