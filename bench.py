@@ -115,27 +115,44 @@ class Workload:
         self.hs = pbrs_amd.HostScene(sb)
         ctx.upload(self.hs)  # scene resident in HBM before any timed region
         self.my_rows = tiling.packed_height(self.H, world, rank)
-        self.out_dev = torch.empty((max(self.my_rows, 1), self.W, 3), dtype=torch.float32, device=dev)
+        # two device buffers: a rank renders frame n + 1 while the rows of frame n travel to the host and into the frame
+        self.out_dev = [torch.empty((max(self.my_rows, 1), self.W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
         self.out_host = torch.empty((max(self.my_rows, 1), self.W, 3), dtype=torch.float32).pin_memory()
         self.bands = (tiling.BAND_ROWS, world, rank) if world > 1 else None
         # one node: the ranks write their rows into a frame in shared memory (no data through gloo); otherwise gloo gather
         self.shared = tiling.SharedFrame.create(self.W, self.H, world, rank) if world > 1 else None
         self.gather_s = 0.0
 
-    def step(self, timing=False, counters=False):
+    def _launch(self, buf, timing, counters):
+        """Queues one frame of this rank's rows on the context's stream (asynchronous)."""
         a = self.args
         if self.my_rows:
-            self.ctx.render_device(self.out_dev.data_ptr(), self.sx, self.sy, self.depth, a.seed, tile=(0, 0, self.W, self.my_rows), bands=self.bands,
-                                   samples_per_pass=a.samples_per_pass, timing=timing, counters=counters, integrator=a.integrator)
-        self.torch.cuda.synchronize()
+            self.ctx.render_device(self.out_dev[buf].data_ptr(), self.sx, self.sy, self.depth, a.seed, tile=(0, 0, self.W, self.my_rows),
+                                   bands=self.bands, samples_per_pass=a.samples_per_pass, timing=timing, counters=counters, integrator=a.integrator)
+
+    def _deliver(self, buf):
+        """Rows of a finished frame: device -> pinned host -> the frame (shared memory, or gloo gather).  Rank 0 gets the frame."""
         t = time.perf_counter()
-        self.out_host.copy_(self.out_dev)
+        self.out_host.copy_(self.out_dev[buf])  # torch's stream: does not wait for the next frame on the context's stream
         if self.shared is not None:
             frame = self.shared.publish(self.out_host.numpy()[:self.my_rows])
         else:
             frame = self.tiling.gather_frame(self.out_host.numpy()[:self.my_rows], self.W, self.H, self.world, self.rank)
         self.gather_s += time.perf_counter() - t
         return frame
+
+    def frames(self, n, timing=False, counters=False):
+        """n consecutive frames.  Frame k + 1 is queued on the GPU before frame k's rows are copied out and handed over, so
+        the hand-over (D2H copy, row scatter, waiting for the slowest rank) hides behind rendering; the shared frame is
+        double-buffered for exactly this one frame of lead.  Returns (last frame on rank 0, list of per-frame stats)."""
+        stats, frame = [], None
+        self._launch(0, timing, counters)
+        for k in range(n):
+            stats.append(self.ctx.collect_stats() if self.my_rows else None)  # waits for frame k on the context's stream
+            if k + 1 < n:
+                self._launch((k + 1) % 2, timing, counters)
+            frame = self._deliver(k % 2)
+        return frame, stats
 
     def barrier(self):
         if self.world > 1:
@@ -147,15 +164,13 @@ class Workload:
         from pbrs_amd import roofline
         torch, dist, world, rank = self.torch, self.dist, self.world, self.rank
         # the first frame allocates the path state (tens of GB): it is never a timed one, whatever --warmup says
-        for _ in range(max(warmup, 1)):
-            self.step()
+        self.frames(max(warmup, 1))
         self.barrier()
         self.gather_s = 0.0
         t0 = time.perf_counter()
         stage_ms, launches = None, None
-        for _ in range(steps):
-            self.step(timing=True)
-            st = self.ctx.collect_stats() if self.my_rows else None
+        _, per_frame = self.frames(steps, timing=True)
+        for st in per_frame:
             if st is not None:
                 if stage_ms is None:
                     stage_ms = {k: 0.0 for k in st if k.startswith("ms_")}
@@ -173,8 +188,7 @@ class Workload:
             elapsed, gather_ms = float(t[0].item()), float(t[1].item())
 
         # Untimed: instrumented frame for ray / node / primitive counts (deterministic, equal to the timed work).
-        frame = self.step(counters=True)
-        cst = self.ctx.collect_stats() if self.my_rows else None
+        frame, (cst,) = self.frames(1, counters=True)
         counts = np.array([cst["closest_rays"], cst["shadow_rays"], cst["samples"], cst["invalid_samples"]] if cst else [0, 0, 0, 0], dtype=np.float64)
         if world > 1:
             tc = torch.from_numpy(counts)

@@ -482,7 +482,9 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     pbrs_ctx* c = new pbrs_ctx();
     c->device = device_ordinal;
     // every failure below leaves through pbrs_destroy, which releases whatever had been created by then
-    bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess;
+    // a non-blocking stream: work another library queues on the legacy default stream (torch's copies in bench.py) neither
+    // waits for the frames queued here nor holds them up
+    bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
     c->stream = c->own_stream;
     if (const char* e = getenv("PBRS_SORT_CLASSES")) c->sort_classes = std::atoi(e) != 0;
     for (int k = 0; ok && k < 2; ++k) {
