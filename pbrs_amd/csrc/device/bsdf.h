@@ -150,8 +150,11 @@ PD f3 beckmann_sample_wh(float ax, float ay, f3 wo, float u, float v) {         
 }
 
 // ---- lobes ----------------------------------------------------------------------------------------------------------
-// `albedo` is the lobe's colour at this hit: pbrs_bxdf::albedo, or the value of its texture (Bsdf::albedo_at)
-PD f3 bxdf_eval(const pbrs_bxdf& b, f3 albedo, f3 wo, f3 wi) {
+// `albedo` is the lobe's colour at this hit: pbrs_bxdf::albedo, or the value of its texture (Bsdf::albedo_at).
+// `lam` (a compile-time constant in the kernels that pass true: k_shade's PBRS_SHADE_LAMBERT variants, chosen at upload when
+// every lobe of the scene is a Lambertian DiffuseReflect): the lobe's kind need not be read, the other kinds' code is gone.
+PD f3 bxdf_eval(const pbrs_bxdf& b, f3 albedo, f3 wo, f3 wi, bool lam) {
+    if (lam) return albedo * PN_FRAC_1_PI;
     if (b.kind == PBRS_BXDF_SPECULAR) return gray(0.0f);  // :458-460
     if (b.kind == PBRS_BXDF_DIFFUSE) {                    // :540-559
         if (!b.oren_nayar) return albedo * PN_FRAC_1_PI;
@@ -181,9 +184,9 @@ PD f3 bxdf_eval(const pbrs_bxdf& b, f3 albedo, f3 wo, f3 wi) {
     return cmul(albedo * beckmann_d(b.alpha_x, b.alpha_y, wh) * beckmann_g(b.alpha_x, b.alpha_y, wo, wi), refl) *
            pn_weak_recip(4.0f * cos_theta_o * cos_theta_i);
 }
-PD ProbD bxdf_prob(const pbrs_bxdf& b, f3 wo, f3 wi) {
-    if (b.kind == PBRS_BXDF_SPECULAR) return mass(0.0f);  // :503-505
-    if (b.kind == PBRS_BXDF_DIFFUSE) {                    // :566-572
+PD ProbD bxdf_prob(const pbrs_bxdf& b, f3 wo, f3 wi, bool lam) {
+    if (!lam && b.kind == PBRS_BXDF_SPECULAR) return mass(0.0f);  // :503-505
+    if (lam || b.kind == PBRS_BXDF_DIFFUSE) {                    // :566-572
         if (wo.z * wi.z >= 0.0f) return density(wi.z * PN_FRAC_1_PI);
         return density(0.0f);
     }
@@ -220,8 +223,8 @@ PD void specular_refract(const pbrs_bxdf& b, f3 albedo, f3 wo, f3& wi, f3& f) { 
     float f_tr = 1.0f - fresnel_refl_coeff(b, t.z);
     f = (f_tr / pn_abs(t.z)) * albedo;
 }
-PD void bxdf_sample(const pbrs_bxdf& b, f3 albedo, f3 wo, float r0, float r1, f3& f, f3& wi, ProbD& pr) {
-    if (b.kind == PBRS_BXDF_SPECULAR) {  // :462-501
+PD void bxdf_sample(const pbrs_bxdf& b, f3 albedo, f3 wo, float r0, float r1, f3& f, f3& wi, ProbD& pr, bool lam) {
+    if (!lam && b.kind == PBRS_BXDF_SPECULAR) {  // :462-501
         if (b.intrusion == PBRS_REFLECTION) {
             specular_reflect(b, albedo, wo, wi, f);
             pr = mass(1.0f);
@@ -240,10 +243,10 @@ PD void bxdf_sample(const pbrs_bxdf& b, f3 albedo, f3 wo, float r0, float r1, f3
         }
         return;
     }
-    if (b.kind == PBRS_BXDF_DIFFUSE) {  // :560-564
+    if (lam || b.kind == PBRS_BXDF_DIFFUSE) {  // :560-564
         wi = cos_sample_hemisphere(r0, r1);
-        f = bxdf_eval(b, albedo, wo, wi);
-        pr = bxdf_prob(b, wo, wi);
+        f = bxdf_eval(b, albedo, wo, wi, lam);
+        pr = bxdf_prob(b, wo, wi, lam);
         return;
     }
     f3 wh = beckmann_sample_wh(b.alpha_x, b.alpha_y, wo, r0, r1);  // :611-626
@@ -255,7 +258,7 @@ PD void bxdf_sample(const pbrs_bxdf& b, f3 albedo, f3 wo, float r0, float r1, f3
         return;
     }
     float pdf = beckmann_pdf(b.alpha_x, b.alpha_y, wh) / (4.0f * dot(wo, wh));
-    f = bxdf_eval(b, albedo, wo, w);
+    f = bxdf_eval(b, albedo, wo, w, false);
     wi = w;
     pr = density(pdf);
 }
@@ -270,6 +273,7 @@ struct Bsdf {
     // (colour), filled once per vertex by bsdf_bind_textures.  nullptr: every lobe with its own constant colour.
     const uint32_t* hit_lobe;
     const float* hit_albedo;
+    bool lam;  // every lobe is a Lambertian DiffuseReflect and a material has at most one (see bxdf_eval)
     PD const pbrs_bxdf& lobe(uint32_t k) const { return lobes[hit_lobe ? hit_lobe[k * 256u] : k]; }
     PD f3 albedo_at(uint32_t k) const {
         if (hit_albedo) return mk3(hit_albedo[(3u * k) * 256u], hit_albedo[(3u * k + 1u) * 256u], hit_albedo[(3u * k + 2u) * 256u]);
@@ -287,17 +291,19 @@ PD Bsdf bsdf_new_frame(const Isect& is, const pbrs_bxdf* lobes, uint32_t n) {  /
     b.n = n;
     b.hit_lobe = nullptr;
     b.hit_albedo = nullptr;
+    b.lam = false;
     return b;
 }
 PD f3 world_to_local(const Bsdf& b, f3 w) { return hat(mk3(dot(b.c0, w), dot(b.c1, w), dot(b.c2, w))); }  // :114-118
 PD f3 local_to_world(const Bsdf& b, f3 l) { return l.x * b.c0 + l.y * b.c1 + l.z * b.c2; }                 // :120-124
 // src/bsdf.rs:104-113: the first Specular lobe sampled with rnd2 = (0.0, 0.0); false when the material has none
 PD bool bsdf_sample_specular(const Bsdf& b, f3 wo_world, f3& f, f3& wi_out, ProbD& pr) {
+    if (b.lam) return false;
     f3 wo = world_to_local(b, wo_world);
     for (uint32_t i = 0; i < b.n; ++i) {
         if (b.lobe(i).kind == PBRS_BXDF_SPECULAR) {
             f3 wi;
-            bxdf_sample(b.lobe(i), b.albedo_at(i), wo, 0.0f, 0.0f, f, wi, pr);
+            bxdf_sample(b.lobe(i), b.albedo_at(i), wo, 0.0f, 0.0f, f, wi, pr, false);
             wi_out = local_to_world(b, wi);
             return true;
         }
@@ -310,14 +316,14 @@ PD f3 bsdf_eval_l(const Bsdf& b, f3 wo, f3 wi_w) {                              
     f3 wi = world_to_local(b, wi_w);
     if (wo.z == 0.0f) return gray(0.0f);
     f3 sum = gray(0.0f);
-    for (uint32_t i = 0; i < b.n; ++i) sum = sum + bxdf_eval(b.lobe(i), b.albedo_at(i), wo, wi);
+    for (uint32_t i = 0; i < b.n; ++i) sum = sum + bxdf_eval(b.lobe(i), b.albedo_at(i), wo, wi, b.lam);
     return sum;
 }
 PD f3 bsdf_eval(const Bsdf& b, f3 wo_w, f3 wi_w) { return bsdf_eval_l(b, world_to_local(b, wo_w), wi_w); }
 PD float bsdf_pdf_l(const Bsdf& b, f3 wo, f3 wi_w) {  // :53-57 (Q7)
     f3 wi = world_to_local(b, wi_w);
     float sum = 0.0f;
-    for (uint32_t i = 0; i < b.n; ++i) sum += dens_of(bxdf_prob(b.lobe(i), wo, wi));
+    for (uint32_t i = 0; i < b.n; ++i) sum += dens_of(bxdf_prob(b.lobe(i), wo, wi, b.lam));
     return sum;
 }
 PD float bsdf_pdf(const Bsdf& b, f3 wo_w, f3 wi_w) { return bsdf_pdf_l(b, world_to_local(b, wo_w), wi_w); }
@@ -333,7 +339,7 @@ PD void bsdf_sample_l(const Bsdf& b, f3 wo, float u, float v, f3& f, f3& wi_out,
     float remapped_u = pn_fract(u * n);
     f3 bsdf_value, wi;
     ProbD prob;
-    bxdf_sample(b.lobe(chosen), b.albedo_at(chosen), wo, v, remapped_u, bsdf_value, wi, prob);  // Q8: (v, remapped_u)
+    bxdf_sample(b.lobe(chosen), b.albedo_at(chosen), wo, v, remapped_u, bsdf_value, wi, prob, b.lam);  // Q8: (v, remapped_u)
     if (prob.is_mass) {
         f = bsdf_value;
         wi_out = local_to_world(b, wi);
@@ -341,13 +347,13 @@ PD void bsdf_sample_l(const Bsdf& b, f3 wo, float u, float v, f3& f, f3& wi_out,
         return;
     }
     // `swap_remove(chosen)`: the others are visited as [0 .. chosen-1, last, chosen+1 .. n-2].
-    uint32_t others = b.n - 1;
+    uint32_t others = b.lam ? 0u : b.n - 1;  // lam: one lobe at most
     uint32_t count = 0;
     float other_pdf_sum = 0.0f;
     f3 other_f = gray(0.0f);
     for (uint32_t k = 0; k < others; ++k) {
         uint32_t idx = (k == chosen) ? (b.n - 1) : k;
-        ProbD p = bxdf_prob(b.lobe(idx), wo, wi);
+        ProbD p = bxdf_prob(b.lobe(idx), wo, wi, false);
         if (!p.is_mass) {
             count += 1;
             other_pdf_sum += p.v;
@@ -355,7 +361,7 @@ PD void bsdf_sample_l(const Bsdf& b, f3 wo, float u, float v, f3& f, f3& wi_out,
     }
     for (uint32_t k = 0; k < others; ++k) {
         uint32_t idx = (k == chosen) ? (b.n - 1) : k;
-        other_f = other_f + bxdf_eval(b.lobe(idx), b.albedo_at(idx), wo, wi);
+        other_f = other_f + bxdf_eval(b.lobe(idx), b.albedo_at(idx), wo, wi, false);
     }
     float overall_pdf = (prob.v + other_pdf_sum) / (float)(1 + count);
     f = bsdf_value + other_f;

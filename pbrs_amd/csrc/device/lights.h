@@ -18,9 +18,12 @@ struct LightPoint {
     f3 pos, normal;
 };
 
-PD bool light_shape_intersect(const pbrs_area_light& L, f3 o, f3 d, LightPoint& out) {
+// `kind`: the light's shape kind — L.shape_kind, or a compile-time constant in the k_shade variants for scenes whose area
+// lights all have one shape (PBRS_SHADE_LIGHT_*, chosen at upload): the record's kind need not be read and the other
+// shapes' sampling and intersection code is gone.
+PD bool light_shape_intersect(const pbrs_area_light& L, uint32_t kind, f3 o, f3 d, LightPoint& out) {
     const float* p = L.p;
-    switch (L.shape_kind) {
+    switch (kind) {
         case PBRS_SHAPE_SPHERE: {
             float t;
             if (!sphere_hit_t(ld3(p), p[3], o, d, pn_inf(), t)) return false;
@@ -97,9 +100,9 @@ PD bool sphere_pdf_at(f3 center, float radius, f3 ref_pos, f3 wi, float& pdf) { 
     return false;
 }
 
-PD LightPoint light_sample_towards(const pbrs_area_light& L, const Isect& target, float u, float v) {
+PD LightPoint light_sample_towards(const pbrs_area_light& L, uint32_t kind, const Isect& target, float u, float v) {
     const float* p = L.p;
-    switch (L.shape_kind) {
+    switch (kind) {
         case PBRS_SHAPE_SPHERE: return sphere_sample_towards(ld3(p), p[3], target.pos, u, v);
         case PBRS_SHAPE_DISK: {  // :258-269
             float cos_t, sin_t;
@@ -126,12 +129,12 @@ PD LightPoint light_sample_towards(const pbrs_area_light& L, const Isect& target
         }
     }
 }
-PD bool light_pdf_at(const pbrs_area_light& L, const Isect& reference, f3 wi, float& pdf) {
-    if (L.shape_kind == PBRS_SHAPE_SPHERE) return sphere_pdf_at(ld3(L.p), L.p[3], reference.pos, wi, pdf);
+PD bool light_pdf_at(const pbrs_area_light& L, uint32_t kind, const Isect& reference, f3 wi, float& pdf) {
+    if (kind == PBRS_SHAPE_SPHERE) return sphere_pdf_at(ld3(L.p), L.p[3], reference.pos, wi, pdf);
     f3 o, d;  // default impl :28-33 (Q4: distance, not distance squared)
     spawn_ray(reference, wi, o, d);
     LightPoint hit;
-    if (!light_shape_intersect(L, o, d, hit)) return false;
+    if (!light_shape_intersect(L, kind, o, d, hit)) return false;
     pdf = norm(reference.pos - hit.pos) / (pn_abs(dot(hit.normal, -wi)) * L.area);
     return true;
 }
@@ -148,20 +151,20 @@ PD ShadowRay limited_ray_to(const Isect& is, f3 pos) {  // spawn_limited_ray_to
 }
 
 // DiffuseAreaLight::sample_incident_radiance (light/src/lib.rs:158-172)
-PD void area_sample_incident(const pbrs_area_light& L, const Isect& target, float u, float v, f3& li, f3& wi, float& pdf, ShadowRay& vis) {
-    LightPoint pt = light_sample_towards(L, target, u, v);
+PD void area_sample_incident(const pbrs_area_light& L, uint32_t kind, const Isect& target, float u, float v, f3& li, f3& wi, float& pdf, ShadowRay& vis) {
+    LightPoint pt = light_sample_towards(L, kind, target, u, v);
     wi = hat(pt.pos - target.pos);
     li = !pn_sign_negative(dot(pt.normal, -wi)) ? ld3(L.emit) : gray(0.0f);  // radiance_from :127-133
-    if (!light_pdf_at(L, target, wi, pdf)) pdf = 0.0f;
+    if (!light_pdf_at(L, kind, target, wi, pdf)) pdf = 0.0f;
     vis = limited_ray_to(target, pt.pos);
 }
 // DiffuseAreaLight::radiance_to (:141-146)
-PD bool area_radiance_to(const pbrs_area_light& L, const Isect& target, f3 wi, f3& le, float& pdf, ShadowRay& vis) {
+PD bool area_radiance_to(const pbrs_area_light& L, uint32_t kind, const Isect& target, f3 wi, f3& le, float& pdf, ShadowRay& vis) {
     f3 o, d;
     spawn_ray(target, wi, o, d);
     LightPoint hit;
-    if (!light_shape_intersect(L, o, d, hit)) return false;
-    if (L.shape_kind == PBRS_SHAPE_SPHERE) {
+    if (!light_shape_intersect(L, kind, o, d, hit)) return false;
+    if (kind == PBRS_SHAPE_SPHERE) {
         if (!sphere_pdf_at(ld3(L.p), L.p[3], target.pos, wi, pdf)) return false;
     } else {
         // the default pdf_at (sample_shape.rs:28-33) spawns the same ray from the same point and intersects the same

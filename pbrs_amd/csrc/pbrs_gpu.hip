@@ -64,6 +64,7 @@ struct pbrs_ctx {
     pbrs_stats pending{};
     bool pending_counters = false, pending_times = false;
     bool textured = false;  // the uploaded scene evaluates non-Solid textures: k_shade<.., true>
+    uint32_t shade_spec = 0;       // PBRS_SHADE_*: what k_shade<PATH> may leave out for this scene
     bool long_walks = false;       // a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: the PBRS_FEAT_LONG_WALKS kernels
     bool shadow_flat = false;      // k_shadow scans the TLAS leaves (up to PBRS_FLAT_TLAS_MAX_ANYHIT instances; k_extend: S.features)
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
@@ -360,19 +361,29 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         if (sorted)
             hipLaunchKernelGGL(k_class_sort, dim3((N + PBRS_SORT_TILE - 1) / PBRS_SORT_TILE), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
         {
-#define PBRS_LAUNCH_SHADE(I, T)                                                                                                  \
-    hipLaunchKernelGGL((k_shade<I, T>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, cnt_in, N, act + b + 1, neeq, ns + b, sorted)
+#define PBRS_LAUNCH_SHADE(I, T, SP)                                                                                                       \
+    hipLaunchKernelGGL((k_shade<I, T, SP>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, cnt_in, N, act + b + 1, neeq, ns + b, sorted)
             const bool direct = rc.integrator == PBRS_INTEGRATOR_DIRECT;
             if (rc.integrator == PBRS_INTEGRATOR_MATERIALS) {
-                PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false);
+                PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false, 0u);
             } else if (rc.integrator == PBRS_INTEGRATOR_NORMALS) {
-                PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_NORMALS, false);
+                PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_NORMALS, false, 0u);
             } else if (c->textured) {  // some material evaluates a non-Solid texture per hit
-                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true);
-                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true);
-            } else {
-                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, false);
-                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false);
+                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true, 0u);
+                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true, 0u);
+            } else if (direct) {
+                PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, false, 0u);
+            } else {  // the path integrator, specialised on what the scene's materials and lights are (c->shade_spec)
+                switch (c->shade_spec) {
+                    case PBRS_SHADE_LAMBERT: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT); break;
+                    case PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_SPHERE:
+                        PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_SPHERE);
+                        break;
+                    case PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_TRIANGLE:
+                        PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_TRIANGLE);
+                        break;
+                    default: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, 0u); break;
+                }
             }
 #undef PBRS_LAUNCH_SHADE
         }
@@ -726,6 +737,31 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         } else if (in.shape_kind != PBRS_SHAPE_TRIANGLE) {  // isolated triangles go through the triangle-record path
             S.features |= PBRS_FEAT_ANALYTIC;
         }
+    }
+    // k_shade specialisation: every lobe an untextured Lambertian DiffuseReflect (at most one per material); every area light
+    // of one shape
+    {
+        bool lambert = !textured;
+        for (uint32_t i = 0; i < d->n_materials && lambert; ++i) {
+            const pbrs_material& m = d->materials[i];  // its lobes only: the array also holds the visualisers' records
+            lambert = m.n_bxdfs <= 1;
+            for (uint32_t k = 0; k < m.n_bxdfs && lambert; ++k) {
+                const pbrs_bxdf& bx = d->bxdfs[m.first_bxdf + k];
+                lambert = bx.kind == PBRS_BXDF_DIFFUSE && bx.oren_nayar == 0 && bx.tex == 0;
+            }
+        }
+        uint32_t spec = lambert ? PBRS_SHADE_LAMBERT : 0u;
+        // the light shape alone does not pay: without the Lambert cut the kernel grows to 135-141 VGPRs, three waves per SIMD
+        // (C2 shade 110.5 -> 117.0 ms, C4 150.6 -> 169.3)
+        if (lambert && d->n_area_lights) {
+            const uint32_t k0 = d->area_lights[0].shape_kind;
+            bool same = true;
+            for (uint32_t i = 1; i < d->n_area_lights; ++i) same = same && d->area_lights[i].shape_kind == k0;
+            if (same && k0 == PBRS_SHAPE_SPHERE) spec |= PBRS_SHADE_LIGHT_SPHERE;
+            if (same && k0 == PBRS_SHAPE_TRIANGLE) spec |= PBRS_SHADE_LIGHT_TRIANGLE;
+        }
+        if (const char* e = getenv("PBRS_SHADE_SPEC")) spec &= (uint32_t)std::atoi(e);  // developer override (A/B timing): a mask
+        c->shade_spec = spec;
     }
     c->S = S;
     c->textured = textured;
