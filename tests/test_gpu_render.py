@@ -156,6 +156,44 @@ def _parallel_quad_scene(textured):
     return sb
 
 
+@pytest.mark.parametrize("lights", ["mixed", "disks", "delta_only", "env_only"])
+def test_lambert_only_scenes_with_other_lights_than_the_baseline(gpu_ctx, lights):
+    """The Lambert variant of k_shade without a light-shape cut (PBRS_SHADE_LAMBERT alone): every material one Lambertian lobe,
+    area lights of several shapes — or of one shape that has no variant of its own, or none at all.  (C1 / C4 run the
+    Lambert + sphere variant, C2 the Lambert + triangle one, everything else in this file the general kernel.)"""
+    from pbrs_amd.spec import SceneBuilder, Transform, deg
+    sb = SceneBuilder()
+    sb.instance(scenes.quad_mesh(sb, (-8, 0, -8), (8, 0, -8), (-8, 0, 8), (8, 0, 8), (0, 1, 0)), sb.lambertian((0.5, 0.5, 0.45)))
+    sb.instance(sb.sphere((0, 0, 0), 1.0), sb.lambertian((0.7, 0.3, 0.2)), Transform.translater((-2.0, 1.0, 0.5)))
+    sb.instance(sb.cuboid((-0.7, 0, -0.7), (0.7, 1.5, 0.7)), sb.lambertian((0.2, 0.6, 0.3)), Transform().rotate_y(deg(30)).translate((1.8, 0, 0.3)))
+    sb.instance(scenes.box_mesh(sb, (-0.5, 0, -0.5), (0.5, 0.8, 0.5)), sb.lambertian((0.3, 0.3, 0.8)), Transform().rotate_y(deg(-20)).translate((0, 0, -1.5)))
+
+    def light(shape, e):
+        sb.instance(shape, sb.diffuse_light(e))
+        sb.area_light(e, shape)
+    if lights == "mixed":
+        light(sb.sphere((2.5, 4.5, -1.0), 0.5), (9.0, 8.0, 7.0))
+        light(sb.disk((-2.0, 5.0, 1.0), (0, -1, 0), (0.9, 0, 0)), (6.0, 6.0, 9.0))
+        light(sb.triangle((1, 5.5, 2), (1, 5.5, 0), (-1, 5.5, 1)), (8.0, 8.0, 8.0))
+        sb.area_light((5.0, 5.0, 5.0), sb.quad((-1, 6, -1), (2, 0, 0), (0, 0, 2)))
+        sb.point_light((0, 3, -3), (10, 10, 10))
+    elif lights == "disks":
+        light(sb.disk((-2.0, 5.0, 1.0), (0, -1, 0), (0.9, 0, 0)), (6.0, 6.0, 9.0))
+        light(sb.disk((2.0, 4.0, -1.0), (0, -1, 0), (0.6, 0, 0)), (9.0, 7.0, 5.0))
+    elif lights == "delta_only":
+        sb.point_light((0, 3, -3), (20, 20, 20))
+        sb.distant_light((0.3, -1.0, 0.4), (1.5, 1.5, 1.2), 12.0)
+    else:
+        sb.env = (0.4, 0.5, 0.7)
+    sb.set_camera(72, 48, deg(55.0), (0, 2.5, -7), (0, 1, 0))
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    img, st = gpu_ctx.render(2, 2, 6, 23, counters=True)
+    ref, ost = OracleScene(sb).render(2, 2, 6, 23)
+    assert ost["tlas_ties"] == 0 and st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    nan = np.isnan(ref)
+    assert (nan == np.isnan(img)).all() and (bits(img)[~nan] == bits(ref)[~nan]).all()
+
+
 @pytest.mark.parametrize("n_objects,n_lights", [(9, 9), (10, 9), (15, 15), (16, 15)])
 def test_scan_limits_of_the_two_traversal_kernels(gpu_ctx, n_objects, n_lights):
     """C5's scene family at 20, 21, 32 and 33 instances: k_extend scans the TLAS leaves up to 20 instances, k_shadow up to 32,
