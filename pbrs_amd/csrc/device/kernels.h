@@ -27,6 +27,11 @@ struct PathState {
     float4* q[2][3];
     float4* hit;  // [i] = t, inst (0xffffffff: miss), prim, shading class   written by k_extend at the ray's queue position
     uint32_t* perm;  // scenes with several shading classes: k_shade's lane j shades the path at queue position perm[j] (k_class_sort)
+    // class-major order (scenes whose Lambertian class gets the Lambert variant of k_shade): per tile and class, the count
+    // and then the offset inside the class; per class (and, at [PBRS_MAX_CLASSES], for all classes but the Lambertian) the
+    // range of lanes that shade it
+    uint32_t* tile_hist;
+    uint2* class_range;
     float4* L;    // [slot] = radiance.xyz, w: the direct integrator's 1 / mass (src/directlighting.rs:37), else unused
     // Next-event estimation hand-off.  Shadow rays by position j in the bounce's shadow queue:
     //   sr[0][j] = origin.xyz, t_max        sr[1][j] = dir.xyz, item
@@ -360,7 +365,7 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 #define PBRS_SHADE_LIGHT_TRIANGLE 4u
 template <uint32_t INTEG, bool TEX, uint32_t SPEC>
 __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
-                                              uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count, uint32_t sorted) {
+                                              uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count, uint32_t sorted, const uint2* range) {
     // per-hit lobe lists of textured materials (Bsdf::hit_lobe / hit_albedo); absent from the untextured instantiation
     __shared__ uint32_t s_hit_lobe[TEX ? PBRS_MAX_BXDFS * 256 : 1];
     __shared__ float s_hit_albedo[TEX ? 3 * PBRS_MAX_BXDFS * 256 : 1];
@@ -370,6 +375,12 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
 #endif
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = count ? *count : n_direct;
+    if (range) {  // one launch per group of shading classes: this one's lanes of the class-major permutation (k_class_scatter)
+        const uint2 r = *range;
+        i += r.x;
+        n = r.y;
+        if (blockIdx.x * blockDim.x + r.x >= n) return;  // the grid is sized for the whole queue
+    }
     bool valid = i < n;
     bool alive = false, cast0 = false, cast1 = false;
     uint32_t slot = 0;
@@ -796,6 +807,85 @@ __global__ void __launch_bounds__(256) k_class_sort(PathState st, const uint32_t
             run += k;
         }
     }
+    __syncthreads();
+    for (uint32_t it = base; it < end; it += 256u) {  // every thread of the block takes part in the barriers
+        const uint32_t i = it + threadIdx.x;
+        const bool valid = i < end;
+        const uint32_t cls = valid ? (__float_as_uint(st.hit[i].w) & (PBRS_MAX_CLASSES - 1u)) : 0xffffffffu;
+        uint32_t rank = 0;
+        for (uint32_t c = 0; c < PBRS_MAX_CLASSES; ++c) {
+            const uint64_t m = __ballot(cls == c);
+            if (cls == c) rank = lane_prefix(m);
+            if (lane == 0) s_wave[wave][c] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = s_tot[cls] + rank;
+            for (uint32_t w = 0; w < wave; ++w) pos += s_wave[w][cls];
+            st.perm[pos] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] += s_wave[0][threadIdx.x] + s_wave[1][threadIdx.x] + s_wave[2][threadIdx.x] + s_wave[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// Class-major variant, for scenes whose Lambertian class is shaded by the Lambert variant of k_shade (pbrs_gpu.hip, run_pass):
+// the same stable counting sort, over the whole queue — per-tile histograms (k_class_count), their prefix over the tiles per
+// class (k_class_scan, one block), then the scatter (k_class_scatter).  Classes come in the order 0, 1, ... with class `last`
+// moved to the end, so that "all classes but `last`" is one range of lanes too: class_range[PBRS_MAX_CLASSES].
+__global__ void __launch_bounds__(256) k_class_count(PathState st, const uint32_t* count, uint32_t n_direct) {
+    const uint32_t n = count ? *count : n_direct;
+    const uint32_t base = blockIdx.x * PBRS_SORT_TILE;
+    if (base >= n) return;
+    const uint32_t end = base + PBRS_SORT_TILE < n ? base + PBRS_SORT_TILE : n;
+    __shared__ uint32_t s_tot[PBRS_MAX_CLASSES];
+    if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256u) atomicAdd(&s_tot[__float_as_uint(st.hit[i].w) & (PBRS_MAX_CLASSES - 1u)], 1u);
+    __syncthreads();
+    if (threadIdx.x < PBRS_MAX_CLASSES) st.tile_hist[blockIdx.x * PBRS_MAX_CLASSES + threadIdx.x] = s_tot[threadIdx.x];
+}
+// One block of PBRS_MAX_CLASSES waves: wave c turns class c's per-tile counts into offsets inside the class.
+__global__ void __launch_bounds__(64 * PBRS_MAX_CLASSES) k_class_scan(PathState st, const uint32_t* count, uint32_t n_direct, uint32_t last) {
+    const uint32_t n = count ? *count : n_direct;
+    const uint32_t n_tiles = (n + PBRS_SORT_TILE - 1u) / PBRS_SORT_TILE;
+    const uint32_t c = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    __shared__ uint32_t s_total[PBRS_MAX_CLASSES];
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 64u) {  // wave-uniform trip count
+        const uint32_t t = t0 + lane;
+        const uint32_t v = t < n_tiles ? st.tile_hist[t * PBRS_MAX_CLASSES + c] : 0u;
+        uint32_t x = v;  // inclusive scan over the wave
+        for (uint32_t off = 1; off < 64u; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (t < n_tiles) st.tile_hist[t * PBRS_MAX_CLASSES + c] = carry + x - v;
+        carry += __shfl(x, 63, 64);
+    }
+    if (lane == 0) s_total[c] = carry;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < PBRS_MAX_CLASSES; ++k) {
+            if (k == last) continue;
+            st.class_range[k] = make_uint2(run, run + s_total[k]);
+            run += s_total[k];
+        }
+        st.class_range[PBRS_MAX_CLASSES] = make_uint2(0u, run);  // every class but `last`
+        if (last < PBRS_MAX_CLASSES) st.class_range[last] = make_uint2(run, run + s_total[last]);
+    }
+}
+__global__ void __launch_bounds__(256) k_class_scatter(PathState st, const uint32_t* count, uint32_t n_direct) {
+    const uint32_t n = count ? *count : n_direct;
+    const uint32_t base = blockIdx.x * PBRS_SORT_TILE;
+    if (base >= n) return;
+    const uint32_t end = base + PBRS_SORT_TILE < n ? base + PBRS_SORT_TILE : n;
+    __shared__ uint32_t s_tot[PBRS_MAX_CLASSES];      // running write offset of each class for this tile
+    __shared__ uint32_t s_wave[4][PBRS_MAX_CLASSES];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] = st.class_range[threadIdx.x].x + st.tile_hist[blockIdx.x * PBRS_MAX_CLASSES + threadIdx.x];
     __syncthreads();
     for (uint32_t it = base; it < end; it += 256u) {  // every thread of the block takes part in the barriers
         const uint32_t i = it + threadIdx.x;

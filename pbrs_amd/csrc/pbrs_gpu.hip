@@ -64,6 +64,9 @@ struct pbrs_ctx {
     pbrs_stats pending{};
     bool pending_counters = false, pending_times = false;
     bool textured = false;  // the uploaded scene evaluates non-Solid textures: k_shade<.., true>
+    uint32_t lambert_class = 0;    // shading class of the Lambert-only materials (0: none)
+    uint32_t light_spec = 0;       // PBRS_SHADE_LIGHT_*: every area light has that shape
+    bool split_lambert = true;     // PBRS_SPLIT_LAMBERT=0 in the environment: one general k_shade launch for all classes (A/B timing)
     uint32_t shade_spec = 0;       // PBRS_SHADE_*: what k_shade<PATH> may leave out for this scene
     bool long_walks = false;       // a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: the PBRS_FEAT_LONG_WALKS kernels
     bool shadow_flat = false;      // k_shadow scans the TLAS leaves (up to PBRS_FLAT_TLAS_MAX_ANYHIT instances; k_extend: S.features)
@@ -133,7 +136,9 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         auto align = [](size_t b) { return (b + 255) / 256 * 256; };
         const size_t v16 = align(n_slots * sizeof(float4));
         // q[2][3], hit, L, nee[3]: one float4 per path each; sr[3]: two per path; occ: two bytes; nee queue: one word
-        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + 2 * align(n_slots * sizeof(uint32_t));
+        const size_t n_tiles = n_slots / PBRS_SORT_TILE + 1;
+        const size_t sort_bytes = align(n_tiles * PBRS_MAX_CLASSES * sizeof(uint32_t)) + align((PBRS_MAX_CLASSES + 1) * sizeof(uint2));
+        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + 2 * align(n_slots * sizeof(uint32_t)) + sort_bytes;
         hipError_t e = hipMalloc(&c->state_mem, total);
         if (e != hipSuccess) {
             c->state_mem = nullptr;
@@ -154,6 +159,8 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         s.occ[1] = s.occ[0] + n_slots;
         c->neeq = reinterpret_cast<uint32_t*>(take(align(n_slots * sizeof(uint32_t))));
         s.perm = reinterpret_cast<uint32_t*>(take(align(n_slots * sizeof(uint32_t))));
+        s.tile_hist = reinterpret_cast<uint32_t*>(take(align(n_tiles * PBRS_MAX_CLASSES * sizeof(uint32_t))));
+        s.class_range = reinterpret_cast<uint2*>(take(align((PBRS_MAX_CLASSES + 1) * sizeof(uint2))));
         c->st = s;
         c->cap_slots = n_slots;
     }
@@ -358,11 +365,22 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
         // several shading classes (and an integrator that shades): order the queue by class first; counted as shade time
         const uint32_t sorted = (c->S.n_classes > 1u && rc.integrator <= PBRS_INTEGRATOR_DIRECT && c->sort_classes) ? 1u : 0u;
-        if (sorted)
-            hipLaunchKernelGGL(k_class_sort, dim3((N + PBRS_SORT_TILE - 1) / PBRS_SORT_TILE), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
+        // ... and where one of the classes is Lambertian (and the integrator has a Lambert variant), class-major over the whole
+        // queue, so that the class gets a launch of that variant and the other classes one of the general kernel
+        const bool split = sorted && c->lambert_class && c->split_lambert && !c->textured && rc.integrator == PBRS_INTEGRATOR_PATH;
+        const uint32_t n_tiles = (N + PBRS_SORT_TILE - 1) / PBRS_SORT_TILE;
+        if (split) {
+            hipLaunchKernelGGL(k_class_count, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
+            hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64 * PBRS_MAX_CLASSES), 0, c->stream, c->st, cnt_in, N, c->lambert_class);
+            hipLaunchKernelGGL(k_class_scatter, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
+        } else if (sorted) {
+            hipLaunchKernelGGL(k_class_sort, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
+        }
         {
 #define PBRS_LAUNCH_SHADE(I, T, SP)                                                                                                       \
-    hipLaunchKernelGGL((k_shade<I, T, SP>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, cnt_in, N, act + b + 1, neeq, ns + b, sorted)
+    hipLaunchKernelGGL((k_shade<I, T, SP>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, cnt_in, N, act + b + 1, neeq, ns + b, sorted, \
+                       shade_range)
+            const uint2* shade_range = nullptr;
             const bool direct = rc.integrator == PBRS_INTEGRATOR_DIRECT;
             if (rc.integrator == PBRS_INTEGRATOR_MATERIALS) {
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false, 0u);
@@ -373,6 +391,15 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
                 else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true, 0u);
             } else if (direct) {
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, false, 0u);
+            } else if (split) {
+                shade_range = c->st.class_range + c->lambert_class;
+                switch (c->light_spec) {
+                    case PBRS_SHADE_LIGHT_SPHERE: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_SPHERE); break;
+                    case PBRS_SHADE_LIGHT_TRIANGLE: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_TRIANGLE); break;
+                    default: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT); break;
+                }
+                shade_range = c->st.class_range + PBRS_MAX_CLASSES;
+                PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, 0u);
             } else {  // the path integrator, specialised on what the scene's materials and lights are (c->shade_spec)
                 switch (c->shade_spec) {
                     case PBRS_SHADE_LAMBERT: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT); break;
@@ -498,6 +525,7 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
     c->stream = c->own_stream;
     if (const char* e = getenv("PBRS_SORT_CLASSES")) c->sort_classes = std::atoi(e) != 0;
+    if (const char* e = getenv("PBRS_SPLIT_LAMBERT")) c->split_lambert = std::atoi(e) != 0;
     for (int k = 0; ok && k < 2; ++k) {
         hipEvent_t ev = nullptr;
         ok = hipEventCreate(&ev) == hipSuccess;
@@ -676,6 +704,11 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
                 mat_class[m] = (uint32_t)std::min<size_t>(at + 1, PBRS_MAX_CLASSES - 1);
             }
             S.n_classes = (uint32_t)std::min<size_t>(sigs.size(), PBRS_MAX_CLASSES - 1);
+            // the class of the materials that are one untextured Lambertian DiffuseReflect (signature: kind 1, not Oren-Nayar)
+            c->lambert_class = 0;
+            const std::string lam_sig = {(char)('a' + PBRS_BXDF_DIFFUSE), 'a', 'a', 'a', '-'};
+            for (size_t at = 0; at < sigs.size() && at + 1 < PBRS_MAX_CLASSES - 1; ++at)
+                if (sigs[at] == lam_sig) c->lambert_class = (uint32_t)at + 1;
         }
         for (pbrs_instance& in : inst) {
             in.pad[0] = mat_class[in.material];
@@ -750,16 +783,18 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
                 lambert = bx.kind == PBRS_BXDF_DIFFUSE && bx.oren_nayar == 0 && bx.tex == 0;
             }
         }
-        uint32_t spec = lambert ? PBRS_SHADE_LAMBERT : 0u;
-        // the light shape alone does not pay: without the Lambert cut the kernel grows to 135-141 VGPRs, three waves per SIMD
-        // (C2 shade 110.5 -> 117.0 ms, C4 150.6 -> 169.3)
-        if (lambert && d->n_area_lights) {
+        uint32_t light_spec = 0u;
+        if (d->n_area_lights) {
             const uint32_t k0 = d->area_lights[0].shape_kind;
             bool same = true;
             for (uint32_t i = 1; i < d->n_area_lights; ++i) same = same && d->area_lights[i].shape_kind == k0;
-            if (same && k0 == PBRS_SHAPE_SPHERE) spec |= PBRS_SHADE_LIGHT_SPHERE;
-            if (same && k0 == PBRS_SHAPE_TRIANGLE) spec |= PBRS_SHADE_LIGHT_TRIANGLE;
+            if (same && k0 == PBRS_SHAPE_SPHERE) light_spec = PBRS_SHADE_LIGHT_SPHERE;
+            if (same && k0 == PBRS_SHAPE_TRIANGLE) light_spec = PBRS_SHADE_LIGHT_TRIANGLE;
         }
+        c->light_spec = light_spec;
+        // the light shape alone does not pay: without the Lambert cut the kernel grows to 135-141 VGPRs, three waves per SIMD
+        // (C2 shade 110.5 -> 117.0 ms, C4 150.6 -> 169.3)
+        uint32_t spec = lambert ? (PBRS_SHADE_LAMBERT | light_spec) : 0u;
         if (const char* e = getenv("PBRS_SHADE_SPEC")) spec &= (uint32_t)std::atoi(e);  // developer override (A/B timing): a mask
         c->shade_spec = spec;
     }
