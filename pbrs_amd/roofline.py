@@ -75,9 +75,11 @@ STAGES = {
 }
 
 
-def kernel_traffic(traffic_doc, kernel):
-    """Average measured HBM bytes per launch of the uninstrumented instantiation(s) of `kernel` in a traffic document
-    (tools/traffic_from_pmc.py), e.g. "k_extend<false, 4u>", "k_shade<0u, false>"; None when absent."""
+def kernel_traffic(traffic_doc, kernel, stage_launches_per_frame=None):
+    """Measured HBM bytes per stage launch of the uninstrumented instantiation(s) of `kernel` in a traffic document
+    (tools/traffic_from_pmc.py), e.g. "k_extend<false, 4u>", "k_shade<0u, false, 5u>"; None when absent.  A stage launch may be
+    several kernel launches (k_shade's variants over their class ranges): the bytes of all of them, over the frames the
+    document covers, divided by the stage's launches in those frames."""
     if not traffic_doc:
         return None
     rows = [v for k, v in traffic_doc.get("kernels", {}).items()
@@ -85,7 +87,11 @@ def kernel_traffic(traffic_doc, kernel):
     n = sum(v["launches"] for v in rows)
     if not n:
         return None
-    return sum(v["hbm_total"] * v["launches"] for v in rows) / n
+    total = sum(v["hbm_total"] * v["launches"] for v in rows)
+    frames = traffic_doc.get("geometry", {}).get("frames")
+    if stage_launches_per_frame and frames:
+        return total / (frames * stage_launches_per_frame)
+    return total / n
 
 
 def stage_report(counters, times, scene_nbytes=0, traffic_doc=None):
@@ -97,7 +103,7 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None):
         launches = max(int(times[launch_key]), 1)
         q = float(qfn(counters)) / launches
         sc = float(sfn(counters)) / launches
-        traffic = kernel_traffic(traffic_doc, kernel)
+        traffic = kernel_traffic(traffic_doc, kernel, launches)
         if scene_nbytes <= L2_BYTES_PER_XCD or sc == 0.0:
             miss, miss_src = 0.0, "scene resident in every XCD's L2" if sc else "no scene reads"
         elif traffic is None:

@@ -33,6 +33,14 @@ def test_scene_misses_come_from_measured_traffic_and_are_capped():
     assert small["extend"]["scene_miss_bytes_per_launch"] == 0 and small["shadow"]["scene_miss_bytes_per_launch"] == 0
 
 
+def test_a_stage_launch_made_of_several_kernel_launches():
+    """k_shade's variants over their class ranges: two kernel launches per bounce, one stage launch."""
+    doc = {"geometry": {"frames": 2}, "kernels": {"k_shade<0u, false, 5u>": {"launches": 4, "hbm_total": 300.0},
+                                                    "k_shade<0u, false, 0u>": {"launches": 4, "hbm_total": 100.0}}}
+    assert roofline.kernel_traffic(doc, "k_shade", stage_launches_per_frame=2) == (4 * 300.0 + 4 * 100.0) / (2 * 2)
+    assert roofline.kernel_traffic(doc, "k_shade") == 200.0  # without the stage's launch count: the plain average
+
+
 def test_fractions_are_fractions_of_the_hbm_peak():
     rep = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30)
     for r in rep.values():
