@@ -124,12 +124,12 @@ typedef struct pbrs_tri_shade {
 
 /* geometry/src/bxdf.rs:263-269 flattened: `bxdfs_at` is constant per material when its textures are Solid; a lobe whose
  * colour comes from another texture names it in `tex` and the colour is evaluated per hit (material/src/lib.rs). */
-enum pbrs_bxdf_kind { PBRS_BXDF_SPECULAR = 0, PBRS_BXDF_DIFFUSE = 1, PBRS_BXDF_MICROFACET = 2 };
+enum pbrs_bxdf_kind { PBRS_BXDF_SPECULAR = 0, PBRS_BXDF_DIFFUSE = 1, PBRS_BXDF_MICROFACET = 2, PBRS_BXDF_FOURIER = 3 };
 enum pbrs_intrusion { PBRS_REFLECTION = 0, PBRS_TRANSMISSION = 1, PBRS_HYBRID = 2 };        /* bxdf.rs:35-40  */
 enum pbrs_fresnel_kind { PBRS_FRESNEL_NOP = 0, PBRS_FRESNEL_DIELECTRIC = 1, PBRS_FRESNEL_CONDUCTOR = 2 }; /* :284-289 */
 typedef struct pbrs_bxdf {
     uint32_t kind;
-    uint32_t intrusion;   /* Specular only */
+    uint32_t intrusion;   /* Specular; Fourier: index into pbrs_scene_desc::fourier_tables */
     uint32_t fresnel;     /* Specular, Microfacet */
     uint32_t oren_nayar;  /* Diffuse: 0 Lambertian, 1 Oren-Nayar */
     float albedo[3];
@@ -168,6 +168,17 @@ typedef struct pbrs_texture {
     uint32_t data; /* offset into tex_floats */
     uint32_t perm; /* offset into tex_words */
 } pbrs_texture;
+
+/* FourierTable (geometry/src/fourier.rs:99-151) after `build`: every array lives in the texture pools.  tex_floats: mu
+ * [n_mu], cdf [n_mu^2], a0 [n_mu^2] (the order-0 cache), a [n_coeffs], recip [m_max] (recip[i] = 1 / i); tex_words:
+ * a_offset [n_mu^2], m_lookup [n_mu^2] (i32 bit patterns, validated non-negative and in range by the host). */
+typedef struct pbrs_fourier_table {
+    uint32_t n_mu, n_channels, m_max;
+    uint32_t mu, cdf, a0, a, recip; /* offsets into tex_floats */
+    uint32_t a_offset, m_lookup;    /* offsets into tex_words  */
+    uint32_t n_coeffs;
+    uint32_t pad;
+} pbrs_fourier_table;
 
 /* light/src/lib.rs:107-111 + light/src/sample_shape.rs:38-43 (world-space shape, area precomputed). */
 typedef struct pbrs_area_light {
@@ -219,6 +230,8 @@ typedef struct pbrs_scene_desc {
     const uint32_t* tex_words;
     uint32_t env_texture;  /* PBRS_ENV_IMAGE: index into textures[] */
     float env_scale[3];
+    uint32_t n_fourier_tables;
+    const pbrs_fourier_table* fourier_tables;
 } pbrs_scene_desc;
 
 /* geometry/src/camera.rs:9-17 with the three `orientation * {c,a,b}` products of shoot_ray (:68-70)

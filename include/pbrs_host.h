@@ -34,8 +34,7 @@ const char* pbrs_host_last_error(void);
 
 /* pbrt-v3 front-end (scene_parser/src/, scene/src/loader.rs:41-879, scene/src/plyloader.rs, PNG image maps): reads the
  * subset of the format the reference supports and produces the plain scene spec that pbrs_host_scene_build consumes.
- * Constructs the reference leaves unimplemented (object instancing, spectral colours, Fourier materials, Loop
- * subdivision, ...) are errors here, reported through pbrs_host_load_error, never aborts. */
+ * Constructs the reference leaves unimplemented (object instancing, spectral colours, Loop subdivision, ...) are errors here, reported through pbrs_host_load_error, never aborts. */
 typedef struct pbrs_loaded_scene pbrs_loaded_scene;
 int pbrs_host_load_pbrt(const char* path, pbrs_loaded_scene** out);
 const pbrs_scene_spec* pbrs_loaded_scene_spec(const pbrs_loaded_scene*); /* borrowed, valid until _free */

@@ -315,6 +315,53 @@ PN_FN float pn_ln(float x) {
 /* f32::hypot for the magnitudes on this path (|x|,|y| <= ~1e18: no overflow handling needed). */
 PN_FN float pn_hypot(float x, float y) { return pn_sqrt(x * x + y * y); }
 /* f32::to_radians: the reference multiplies by the f32 constant PI/180. */
+/* f64::sin_cos for the Newton-bisection of geometry/src/fourier.rs:245-297 (`phi.sin_cos()` on an f64 angle in [0, 2 pi]).
+ * The double-precision Cephes kernels: 3-part Cody-Waite pi/4 reduction, degree-6 polynomials in z = x^2.  Only IEEE
+ * f64 + - * and an integer conversion; valid for |x| < 2^30 (the callers stay inside [0, 2 pi]). */
+PN_FN void pn_sincos_f64(double x, double* s, double* c) {
+    int sign_s = 0, sign_c = 0;
+    double ax = x;
+    if (ax < 0.0) {
+        ax = -ax;
+        sign_s = 1;
+    }
+    if (!(ax < 1073741824.0)) { /* out of the reduction's range (and NaN): no caller gets here */
+        *s = 0.0;
+        *c = 1.0;
+        return;
+    }
+    int64_t j = (int64_t)(ax * 1.27323954473516268615 /* 4 / pi */);
+    if (j & 1) j += 1; /* map zeros to the origin */
+    double y = (double)j;
+    j &= 7;
+    if (j > 3) {
+        sign_s ^= 1;
+        sign_c ^= 1;
+        j -= 4;
+    }
+    if (j > 1) sign_c ^= 1;
+    double z = ((ax - y * 7.85398125648498535156e-1) - y * 3.77489470793079817668e-8) - y * 2.69515142907905952645e-15;
+    double zz = z * z;
+    double ps = 1.58962301576546568060e-10;
+    ps = ps * zz + -2.50507477628578072866e-8;
+    ps = ps * zz + 2.75573136213857245213e-6;
+    ps = ps * zz + -1.98412698295895385996e-4;
+    ps = ps * zz + 8.33333333332211858878e-3;
+    ps = ps * zz + -1.66666666666666307295e-1;
+    double sin_z = z + z * zz * ps;
+    double pc = -1.13585365213876817300e-11;
+    pc = pc * zz + 2.08757008419747316778e-9;
+    pc = pc * zz + -2.75573141792967388112e-7;
+    pc = pc * zz + 2.48015872888517045348e-5;
+    pc = pc * zz + -1.38888888888730564116e-3;
+    pc = pc * zz + 4.16666666666665929218e-2;
+    double cos_z = 1.0 - 0.5 * zz + zz * zz * pc;
+    double sv = (j == 1 || j == 2) ? cos_z : sin_z;
+    double cv = (j == 1 || j == 2) ? sin_z : cos_z;
+    *s = sign_s ? -sv : sv;
+    *c = sign_c ? -cv : cv;
+}
+
 PN_FN float pn_to_radians(float deg) { return deg * (PN_PI / 180.0f); }
 
 /* ---- RNG contract --------------------------------------------------

@@ -74,11 +74,26 @@ enum pbrs_material_kind {
     PBRS_MTL_DIFFUSE_LIGHT = 6, /* p[0..3) emit                                              (:124-132)*/
     PBRS_MTL_UBER = 7,          /* p[0..3) kd, [3..6) ks, [6..9) kr, [9..12) kt, [12] rough_u,
                                    [13] rough_v, [14] eta, [15] opacity; flags 1,2,4         (:302-369)*/
-    PBRS_MTL_SUBSTRATE = 8      /* p[0..3) kd, p[3..6) ks                                    (:371-424)*/
+    PBRS_MTL_SUBSTRATE = 8,     /* p[0..3) kd, p[3..6) ks                                    (:371-424)*/
+    PBRS_MTL_FOURIER = 9        /* tex[0] = index into fourier_tables[] (NOT a texture)      (:451-475)*/
 };
 #define PBRS_MTL_FLAG_REMAP_ROUGHNESS 1u
 #define PBRS_MTL_FLAG_HAS_KR 2u
 #define PBRS_MTL_FLAG_HAS_KT 4u
+
+/* geometry/src/fourier.rs:99-221 — the arrays of a `.bsdf` file (the SCATFUN format of layerlab, :13-51) as
+ * FourierTable::from_file reads them after the 64-byte header; `FourierTable::build` (:115-151) derives m_max, the
+ * order-0 cache and the reciprocal table from them on each side of the boundary. */
+typedef struct pbrs_fourier_table_spec {
+    uint32_t n_mu;       /* header.n_mu: elevational samples (>= 3)                               */
+    uint32_t n_channels; /* 1 (monochromatic) or 3 (luminance, red, blue)                        */
+    uint32_t n_coeffs;   /* header.n_coeffs                                                      */
+    float eta;           /* header.eta (read, asserted finite and never used by the reference)   */
+    const float* mu;                  /* n_mu zenith cosines, ascending                          */
+    const float* cdf;                 /* n_mu * n_mu                                             */
+    const int32_t* offset_and_length; /* n_mu * n_mu pairs: offset into a[], series length m     */
+    const float* a;                   /* n_coeffs: per (mu_o, mu_i) pair n_channels * m values   */
+} pbrs_fourier_table_spec;
 
 typedef struct pbrs_material_spec {
     uint32_t kind;
@@ -141,6 +156,8 @@ typedef struct pbrs_scene_spec {
     uint32_t env_kind;     /* enum pbrs_env_kind; CONSTANT reads env_constant */
     uint32_t env_texture;  /* IMAGE: index into textures[] (an IMAGE texture), looked up at lat-long (u, v) (:108-114) */
     float env_scale[3];    /* IMAGE: `scale_factor` */
+    uint32_t n_fourier_tables;
+    const pbrs_fourier_table_spec* fourier_tables; /* material::Fourier::from_file, one per `.bsdf` file */
 } pbrs_scene_spec;
 /* scene/src/lib.rs:20-24 EnvLight; the `Fn` arm carries one of the closures of scene/src/preset.rs:25-53 */
 enum pbrs_env_kind { PBRS_ENV_CONSTANT = 0, PBRS_ENV_IMAGE = 1, PBRS_ENV_BLUE_SKY = 2, PBRS_ENV_DARK_ROOM = 3, PBRS_ENV_DUSK = 4 };

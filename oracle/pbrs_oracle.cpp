@@ -47,12 +47,18 @@ std::unique_ptr<Scene> scene_from_spec(const pbrs_scene_spec& spec) {
         }
         textures.push_back(tx);
     }
+    std::vector<std::shared_ptr<FourierTable>> fourier_tables;  // material::Fourier::from_file, material/src/lib.rs:455-460
+    for (uint32_t t = 0; t < spec.n_fourier_tables; ++t) fourier_tables.push_back(FourierTable::build(spec.fourier_tables[t]));
     std::vector<std::shared_ptr<Material>> mtls;
     for (uint32_t m = 0; m < spec.n_materials; ++m) {
         auto mt = std::make_shared<Material>();
         mt->spec = spec.materials[m];
-        for (int k = 0; k < 4; ++k)
-            if (spec.materials[m].tex[k]) mt->tex[k] = textures.at(spec.materials[m].tex[k] - 1);
+        if (mt->spec.kind == PBRS_MTL_FOURIER) {
+            mt->fourier = fourier_tables.at(mt->spec.tex[0]);  // an index into fourier_tables[], not a texture
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (spec.materials[m].tex[k]) mt->tex[k] = textures.at(spec.materials[m].tex[k] - 1);
+        }
         mtls.push_back(mt);
     }
     std::vector<std::unique_ptr<Instance>> instances;
@@ -342,6 +348,7 @@ static Color material_visualizer(const Scene& scene, Ray ray) {
         switch (h.inst->mtl->spec.kind) {  // the first arm whose string the summary contains
             case PBRS_MTL_LAMBERTIAN: index = 8; break;     // "Lambertian"
             case PBRS_MTL_METAL: index = 7; break;          // "Metal{ior = ...}"
+            case PBRS_MTL_FOURIER: index = 6; break;        // "Fourier"
             case PBRS_MTL_MIRROR: index = 5; break;         // "Mirror{albedo = ...}"
             case PBRS_MTL_DIELECTRIC: index = 4; break;     // "Dielectric{ior = ...}"
             case PBRS_MTL_DIFFUSE_LIGHT: index = 3; break;  // "DiffuseLight{emit = ...}"

@@ -8,6 +8,7 @@
 // Pointer-linked trees, recursion and virtual-free enum dispatch as in the Rust source; nothing
 // here is shared with the HIP kernels except include/pbrs_numeric.h (the f32 libm contract).
 #pragma once
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -132,8 +133,26 @@ struct MicrofacetDistrib {  // microfacet.rs:10-13
 };
 float roughness_to_alpha(float roughness);  // microfacet.rs:16-23
 
-struct BXDF {  // bxdf.rs:263-269 (Fourier omitted: out of scope)
-    enum Kind { Specular, DiffuseReflect, MicrofacetReflect, FresnelBlend } kind;
+// ---- geometry/src/fourier.rs:99-221 + math/src/spline.rs:187-335 --------------------------------
+struct FourierTable {
+    size_t m_max = 0, n_channels = 0;
+    std::vector<float> mu, cdf, a0;
+    std::vector<int32_t> a_offset, m_lookup;
+    std::vector<float> a, recip;
+    // FourierTable::build(n_channels, mu, cdf, a_offset, m_lookup, coefficients), :115-151
+    static std::shared_ptr<FourierTable> build(const pbrs_fourier_table_spec& t);
+    const float* get_ak(size_t offset_i, size_t offset_o, size_t* m) const;  // :160-165
+};
+size_t find_interval(size_t size, const std::function<bool(size_t)>& predicate);                  // spline.rs:161-185 (range.start)
+bool catmull_rom_weights(const std::vector<float>& nodes, float x, long* offset, float w[4]);     // spline.rs:203-247
+bool sample_catmull_rom_2d(const std::vector<float>& nodes_v, const std::vector<float>& nodes_h, const std::vector<float>& values,
+                           const std::vector<float>& cdf, float alpha, float u, float* fval, float* x, float* pdf);  // :249-318
+float fourier_sum(const float* a, size_t n, float cos_phi);                                       // fourier.rs:224-237
+void sample_fourier(const float* ak, size_t n, const float* recip, float u, float* f, float* phi, float* pdf);  // :245-297
+
+struct BXDF {  // bxdf.rs:263-269
+    enum Kind { Specular, DiffuseReflect, MicrofacetReflect, FresnelBlend, Fourier } kind;
+    const FourierTable* table = nullptr;  // Fourier (fourier.rs:219-221)
     // Specular (:395-399)
     Fresnel fresnel;
     Color albedo;
@@ -193,6 +212,7 @@ struct Texture {
 struct Material {
     pbrs_material_spec spec;
     std::shared_ptr<Texture> tex[4];  // nullptr = the Solid colour in spec.p
+    std::shared_ptr<FourierTable> fourier;  // Fourier (:451-475)
     std::vector<BXDF> bxdfs_at(const Interaction& isect) const;  // per-kind `bxdfs_at`
     Color emission() const;                                      // :24-26, :294-296
 };

@@ -283,7 +283,12 @@ static Color schlick_fresnel(const BXDF& b, float cos_t) {
     return b.specular + pn_powi(1.0f - cos_t, 5) * (gray(1.0f) - b.specular);
 }
 
+Color fourier_eval(const FourierTable& T, Omega wo, Omega wi);  // ref_fourier.cpp
+void fourier_sample(const FourierTable& T, Omega wo, float u, float v, Color* f, Omega* wi_out, Prob* pr);
+Prob fourier_prob(const FourierTable& T, Omega wo, Omega wi);
+
 Color BXDF::eval(Omega wo, Omega wi) const {
+    if (kind == Fourier) return fourier_eval(*table, wo, wi);  // fourier.rs:300-360
     switch (kind) {
         case Specular: return black();  // :458-460
         case DiffuseReflect: {           // :540-559
@@ -330,6 +335,7 @@ Color BXDF::eval(Omega wo, Omega wi) const {
 }
 
 Prob BXDF::prob(Omega wo, Omega wi) const {
+    if (kind == Fourier) return fourier_prob(*table, wo, wi);  // fourier.rs:442-485
     switch (kind) {
         case Specular: return Prob::Mass(0.0f);  // :503-505
         case DiffuseReflect:                     // :566-572
@@ -352,6 +358,7 @@ Prob BXDF::prob(Omega wo, Omega wi) const {
 }
 
 void BXDF::sample(Omega wo, float r0, float r1, Color* f, Omega* wi, Prob* pr) const {
+    if (kind == Fourier) return fourier_sample(*table, wo, r0, r1, f, wi, pr);  // fourier.rs:362-440, rnd2 = (u, v)
     switch (kind) {
         case Specular: {  // :462-501
             if (intrusion == Reflection) {
@@ -654,6 +661,13 @@ std::vector<BXDF> Material::bxdfs_at(const Interaction& isect) const {
         case PBRS_MTL_SUBSTRATE: {  // :393-420 (Q18: degenerates to Lambert)
             Color diff = c3(p), specular = c3(p + 3);
             if (!(is_black(diff) && is_black(specular))) out.push_back(bxdf_lambertian(diff));
+            break;
+        }
+        case PBRS_MTL_FOURIER: {  // :467-470
+            BXDF b{};
+            b.kind = BXDF::Fourier;
+            b.table = fourier.get();
+            out.push_back(b);
             break;
         }
         default: ref_panic();

@@ -4,6 +4,7 @@
 // transcribed with their literals.  They pin the oracle: the Rust reference
 // cannot run here, so these vectors are the only outputs of it that exist.  Tests that draw from
 // the unseeded thread_rng in the reference use the repo's PCG32 contract with a fixed seed here.
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -593,6 +594,98 @@ void mf_refl_test() {
     CHECK(responses > 0, "no sample of the grid had a positive density");
 }
 
+// math/src/spline.rs:384-408 test_find_interval
+void find_interval_test() {
+    const int array[8] = {16, 21, 32, 43, 55, 62, 73, 82};
+    for (int x = 0; x < 10; ++x) {
+        const int pivot = x * 10 + 5;
+        for (int strict = 0; strict < 2; ++strict) {
+            size_t start = find_interval(8, [&](size_t i) { return strict ? array[i] < pivot : array[i] <= pivot; });
+            size_t end = start + 1;
+            if (pivot < array[0]) {
+                CHECK(start == 0, "pivot %d: start %zu", pivot, start);
+            } else if (pivot > array[7]) {
+                CHECK(end == 7, "pivot %d: end %zu", pivot, end);
+            } else if (strict) {
+                CHECK(array[start] < pivot && array[end] >= pivot, "pivot %d: [%zu, %zu]", pivot, start, end);
+            } else {
+                CHECK(array[start] <= pivot && array[end] > pivot, "pivot %d: [%zu, %zu]", pivot, start, end);
+            }
+        }
+    }
+}
+// math/src/spline.rs:410-434 catmull_test (the nodes are the zenith cosines of a real .bsdf table)
+void catmull_test() {
+    const std::vector<float> values = {
+        -1.0f, -0.9992586f, -0.99751526f, -0.9947773f, -0.9910477f, -0.98633015f, -0.98062944f, -0.97395116f, -0.9663021f, -0.95768976f,
+        -0.94812274f, -0.9376106f, -0.9261639f, -0.913794f, -0.9005131f, -0.88633466f, -0.8712726f, -0.85534215f, -0.838559f, -0.82093996f,
+        -0.80250263f, -0.7832653f, -0.7632472f, -0.7424683f, -0.7209493f, -0.69871163f, -0.67577744f, -0.65216964f, -0.62791175f, -0.60302794f,
+        -0.577543f, -0.5514824f, -0.52487206f, -0.49773848f, -0.47010878f, -0.44201043f, -0.4134715f, -0.3845204f, -0.35518602f, -0.32549757f,
+        -0.29548463f, -0.2651772f, -0.23460539f, -0.20379974f, -0.17279093f, -0.14160988f, -0.110287674f, -0.07885553f, -0.04734478f, -0.01578684f,
+        0.0f, 0.0f, 0.01578684f, 0.04734478f, 0.07885553f, 0.110287674f, 0.14160988f, 0.17279093f, 0.20379974f, 0.23460539f,
+        0.2651772f, 0.29548463f, 0.32549757f, 0.35518602f, 0.3845204f, 0.4134715f, 0.44201043f, 0.47010878f, 0.49773848f, 0.52487206f,
+        0.5514824f, 0.577543f, 0.60302794f, 0.62791175f, 0.65216964f, 0.67577744f, 0.69871163f, 0.7209493f, 0.7424683f, 0.7632472f,
+        0.7832653f, 0.80250263f, 0.82093996f, 0.838559f, 0.85534215f, 0.8712726f, 0.88633466f, 0.9005131f, 0.913794f, 0.9261639f,
+        0.9376106f, 0.94812274f, 0.95768976f, 0.9663021f, 0.97395116f, 0.98062944f, 0.98633015f, 0.9910477f, 0.9947773f, 0.99751526f,
+        0.9992586f, 1.0f};
+    std::vector<float> inputs = linspace(-1.1f, 1.1f, 30, nullptr);
+    inputs.push_back((values[0] + values[1]) / 2.0f);
+    int inside = 0;
+    for (float x : inputs) {
+        long il;
+        float w[4];
+        if (!catmull_rom_weights(values, x, &il, w)) {
+            CHECK(x < values.front() || x > values.back(), "None for %g inside the nodes", x);
+            continue;
+        }
+        ++inside;
+        const float weight_sum = w[0] + w[1] + w[2] + w[3];
+        CHECK(pn_abs(weight_sum - 1.0f) < 1e-6f, "weights sum to %g at %g", weight_sum, x);
+        const size_t i0 = (size_t)(il + 1), i1 = (size_t)(il + 2);
+        CHECK(x >= values[i0] && x < values[i1], "%g outside [%g, %g)", x, values[i0], values[i1]);
+    }
+    CHECK(inside >= 27, "only %d of the inputs fell inside the nodes", inside);
+}
+// geometry/src/fourier.rs:494-508 fourier_sum_test: the Chebyshev sum against a_k cos(k phi) term by term
+void fourier_sum_test() {
+    uint64_t rng = pn_rng_init(29, 0, 0);
+    float a[15];
+    for (float& x : a) x = pn_rng_f32(&rng);
+    for (int i = 0; i < 680; ++i) {
+        const float cos_phi = pn_clamp(pn_rng_f32(&rng) * 2.0f - 1.0f, -1.0f, 1.0f);
+        const float phi = pn_acos(cos_phi);
+        float expected = 0.0f;
+        for (int k = 0; k < 15; ++k) expected += a[k] * pn_cos(phi * (float)k);
+        const float actual = fourier_sum(a, 15, cos_phi);
+        CHECK(pn_abs(actual - expected) < 2e-5f, "fourier_sum %g against %g at cos_phi %g", actual, expected, cos_phi);
+    }
+}
+// Not in the reference (its Fourier tests need assets/paint.bsdf, which the snapshot does not hold): sample_fourier on a
+// series that is a probability density up to scale — the sampled angle's CDF is the random number, and the returned
+// density is f(phi) / (2 pi a_0).
+void sample_fourier_inverts_the_cdf() {
+    const float ak[4] = {1.0f, 0.5f, -0.2f, 0.1f};  // positive everywhere: |0.5| + |0.2| + |0.1| < 1
+    float recip[4];
+    for (int i = 0; i < 4; ++i) recip[i] = pn_recip((float)i);
+    for (int i = 0; i < 200; ++i) {
+        const float u = ((float)i + 0.5f) / 200.0f;
+        float f, phi, pdf;
+        sample_fourier(ak, 4, recip, u, &f, &phi, &pdf);
+        const double p = (double)phi;
+        const double fold = p <= 3.141592653589793 ? p : 2.0 * 3.141592653589793 - p;
+        double F = ak[0] * fold;
+        double fv = ak[0];
+        for (int k = 1; k < 4; ++k) {
+            F += ak[k] / k * std::sin(k * fold);
+            fv += ak[k] * std::cos(k * fold);
+        }
+        const double un = u >= 0.5f ? 1.0 - 2.0 * (u - 0.5) : u * 2.0;
+        CHECK(std::fabs(F / (3.141592653589793 * ak[0]) - un) < 2e-6, "u %g: CDF at the sampled angle is %g", u, F / (3.141592653589793 * ak[0]));
+        CHECK((u >= 0.5f) == (p > 3.141592653589793), "u %g on the wrong half: phi %g", u, p);
+        CHECK(std::fabs(f - fv) < 1e-5 && std::fabs(pdf - fv / (2.0 * 3.141592653589793 * ak[0])) < 1e-6, "u %g: f %g pdf %g", u, f, pdf);
+    }
+}
+
 struct Entry {
     const char* name;
     void (*fn)();
@@ -617,6 +710,10 @@ const Entry kTests[] = {
     {"observe_sphere_sample_towards", observe_sphere_sample_towards},
     {"lambertian_test", lambertian_test},
     {"mf_refl_test", mf_refl_test},
+    {"find_interval_test", find_interval_test},
+    {"catmull_test", catmull_test},
+    {"fourier_sum_test", fourier_sum_test},
+    {"sample_fourier_inverts_the_cdf", sample_fourier_inverts_the_cdf},
 };
 const uint32_t kNumTests = sizeof(kTests) / sizeof(kTests[0]);
 

@@ -42,7 +42,8 @@ class SceneDesc(C.Structure):
                 ("n_textures", C.c_uint32), ("textures", C.c_void_p),
                 ("n_tex_floats", C.c_uint32), ("tex_floats", C.c_void_p),
                 ("n_tex_words", C.c_uint32), ("tex_words", C.c_void_p),
-                ("env_texture", C.c_uint32), ("env_scale", C.c_float * 3)]
+                ("env_texture", C.c_uint32), ("env_scale", C.c_float * 3),
+                ("n_fourier_tables", C.c_uint32), ("fourier_tables", C.c_void_p)]
 
 
 class Camera(C.Structure):
@@ -211,7 +212,7 @@ class HostScene:
         d = self.desc
         return (32 * (d.n_tlas_nodes + d.n_blas_nodes) + 128 * d.n_instances + 48 * d.n_shapes + 32 * d.n_meshes +
                 (48 + 64) * d.n_triangles + 32 * d.n_materials + 64 * d.n_bxdfs + 64 * d.n_area_lights + 32 * d.n_delta_lights +
-                48 * d.n_textures + 4 * (d.n_tex_floats + d.n_tex_words))
+                48 * d.n_textures + 4 * (d.n_tex_floats + d.n_tex_words) + 48 * d.n_fourier_tables)
 
     def nodes(self, which="tlas"):
         n, p = (self.desc.n_tlas_nodes, self.desc.tlas_nodes) if which == "tlas" else (self.desc.n_blas_nodes, self.desc.blas_nodes)

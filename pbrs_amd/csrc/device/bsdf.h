@@ -5,8 +5,8 @@
 // geometry/src/microfacet.rs (Beckmann d/lambda/g/pdf/sample_wh :36-159) and src/bsdf.rs:18-124.
 // The reference builds a heap Vec<BXDF> per hit (material/src/lib.rs `bxdfs_at`); with Solid
 // textures that list is constant per material, so it is a flat table in HBM (pbrs_bxdf) indexed by
-// the material record.  FresnelBlend and Fourier are constructed by no material in scope and are
-// not compiled in.
+// the material record.  FresnelBlend is constructed by no material and is not compiled in; the
+// Fourier lobe (device/fourier.h) is compiled into the kernels that scenes with such a material run.
 #pragma once
 #include "shapes.h"
 
@@ -17,6 +17,7 @@ struct ProbD {  // math/src/prob.rs:5-8
 PD ProbD density(float v) { return ProbD{false, v}; }
 PD ProbD mass(float v) { return ProbD{true, v}; }
 PD float dens_of(ProbD p) { return p.is_mass ? 0.0f : p.v; }
+#include "fourier.h"
 
 // ---- Omega (bxdf.rs:42-155) -------------------------------------------------------------------------------
 PD float cos2_theta(f3 w) { return pn_sq(w.z); }
@@ -153,8 +154,11 @@ PD f3 beckmann_sample_wh(float ax, float ay, f3 wo, float u, float v) {         
 // `albedo` is the lobe's colour at this hit: pbrs_bxdf::albedo, or the value of its texture (Bsdf::albedo_at).
 // `lam` (a compile-time constant in the kernels that pass true: k_shade's PBRS_SHADE_LAMBERT variants, chosen at upload when
 // every lobe of the scene is a Lambertian DiffuseReflect): the lobe's kind need not be read, the other kinds' code is gone.
-PD f3 bxdf_eval(const pbrs_bxdf& b, f3 albedo, f3 wo, f3 wi, bool lam) {
+// `fv`: the scene's Fourier tables in the kernels that carry the lobe (k_shade's PBRS_SHADE_FOURIER variants), nullptr — a
+// compile-time constant — in all others.
+PD f3 bxdf_eval(const pbrs_bxdf& b, f3 albedo, f3 wo, f3 wi, bool lam, const FourierView* fv = nullptr) {
     if (lam) return albedo * PN_FRAC_1_PI;
+    if (fv && b.kind == PBRS_BXDF_FOURIER) return fourier_eval(*fv, fv->tables[b.intrusion], wo, wi);  // fourier.rs:300-360
     if (b.kind == PBRS_BXDF_SPECULAR) return gray(0.0f);  // :458-460
     if (b.kind == PBRS_BXDF_DIFFUSE) {                    // :540-559
         if (!b.oren_nayar) return albedo * PN_FRAC_1_PI;
@@ -184,7 +188,8 @@ PD f3 bxdf_eval(const pbrs_bxdf& b, f3 albedo, f3 wo, f3 wi, bool lam) {
     return cmul(albedo * beckmann_d(b.alpha_x, b.alpha_y, wh) * beckmann_g(b.alpha_x, b.alpha_y, wo, wi), refl) *
            pn_weak_recip(4.0f * cos_theta_o * cos_theta_i);
 }
-PD ProbD bxdf_prob(const pbrs_bxdf& b, f3 wo, f3 wi, bool lam) {
+PD ProbD bxdf_prob(const pbrs_bxdf& b, f3 wo, f3 wi, bool lam, const FourierView* fv = nullptr) {
+    if (fv && b.kind == PBRS_BXDF_FOURIER) return fourier_prob(*fv, fv->tables[b.intrusion], wo, wi);  // fourier.rs:442-485
     if (!lam && b.kind == PBRS_BXDF_SPECULAR) return mass(0.0f);  // :503-505
     if (lam || b.kind == PBRS_BXDF_DIFFUSE) {                    // :566-572
         if (wo.z * wi.z >= 0.0f) return density(wi.z * PN_FRAC_1_PI);
@@ -223,7 +228,12 @@ PD void specular_refract(const pbrs_bxdf& b, f3 albedo, f3 wo, f3& wi, f3& f) { 
     float f_tr = 1.0f - fresnel_refl_coeff(b, t.z);
     f = (f_tr / pn_abs(t.z)) * albedo;
 }
-PD void bxdf_sample(const pbrs_bxdf& b, f3 albedo, f3 wo, float r0, float r1, f3& f, f3& wi, ProbD& pr, bool lam) {
+PD void bxdf_sample(const pbrs_bxdf& b, f3 albedo, f3 wo, float r0, float r1, f3& f, f3& wi, ProbD& pr, bool lam,
+                    const FourierView* fv = nullptr) {
+    if (fv && b.kind == PBRS_BXDF_FOURIER) {  // fourier.rs:362-440, rnd2 = (u, v)
+        fourier_sample(*fv, fv->tables[b.intrusion], wo, r0, r1, f, wi, pr);
+        return;
+    }
     if (!lam && b.kind == PBRS_BXDF_SPECULAR) {  // :462-501
         if (b.intrusion == PBRS_REFLECTION) {
             specular_reflect(b, albedo, wo, wi, f);
@@ -274,6 +284,7 @@ struct Bsdf {
     const uint32_t* hit_lobe;
     const float* hit_albedo;
     bool lam;  // every lobe is a Lambertian DiffuseReflect and a material has at most one (see bxdf_eval)
+    const FourierView* fourier;  // the scene's Fourier tables, or nullptr in kernels without the lobe (see bxdf_eval)
     PD const pbrs_bxdf& lobe(uint32_t k) const { return lobes[hit_lobe ? hit_lobe[k * 256u] : k]; }
     PD f3 albedo_at(uint32_t k) const {
         if (hit_albedo) return mk3(hit_albedo[(3u * k) * 256u], hit_albedo[(3u * k + 1u) * 256u], hit_albedo[(3u * k + 2u) * 256u]);
@@ -292,6 +303,7 @@ PD Bsdf bsdf_new_frame(const Isect& is, const pbrs_bxdf* lobes, uint32_t n) {  /
     b.hit_lobe = nullptr;
     b.hit_albedo = nullptr;
     b.lam = false;
+    b.fourier = nullptr;
     return b;
 }
 PD f3 world_to_local(const Bsdf& b, f3 w) { return hat(mk3(dot(b.c0, w), dot(b.c1, w), dot(b.c2, w))); }  // :114-118
@@ -316,14 +328,14 @@ PD f3 bsdf_eval_l(const Bsdf& b, f3 wo, f3 wi_w) {                              
     f3 wi = world_to_local(b, wi_w);
     if (wo.z == 0.0f) return gray(0.0f);
     f3 sum = gray(0.0f);
-    for (uint32_t i = 0; i < b.n; ++i) sum = sum + bxdf_eval(b.lobe(i), b.albedo_at(i), wo, wi, b.lam);
+    for (uint32_t i = 0; i < b.n; ++i) sum = sum + bxdf_eval(b.lobe(i), b.albedo_at(i), wo, wi, b.lam, b.fourier);
     return sum;
 }
 PD f3 bsdf_eval(const Bsdf& b, f3 wo_w, f3 wi_w) { return bsdf_eval_l(b, world_to_local(b, wo_w), wi_w); }
 PD float bsdf_pdf_l(const Bsdf& b, f3 wo, f3 wi_w) {  // :53-57 (Q7)
     f3 wi = world_to_local(b, wi_w);
     float sum = 0.0f;
-    for (uint32_t i = 0; i < b.n; ++i) sum += dens_of(bxdf_prob(b.lobe(i), wo, wi, b.lam));
+    for (uint32_t i = 0; i < b.n; ++i) sum += dens_of(bxdf_prob(b.lobe(i), wo, wi, b.lam, b.fourier));
     return sum;
 }
 PD float bsdf_pdf(const Bsdf& b, f3 wo_w, f3 wi_w) { return bsdf_pdf_l(b, world_to_local(b, wo_w), wi_w); }
@@ -339,7 +351,7 @@ PD void bsdf_sample_l(const Bsdf& b, f3 wo, float u, float v, f3& f, f3& wi_out,
     float remapped_u = pn_fract(u * n);
     f3 bsdf_value, wi;
     ProbD prob;
-    bxdf_sample(b.lobe(chosen), b.albedo_at(chosen), wo, v, remapped_u, bsdf_value, wi, prob, b.lam);  // Q8: (v, remapped_u)
+    bxdf_sample(b.lobe(chosen), b.albedo_at(chosen), wo, v, remapped_u, bsdf_value, wi, prob, b.lam, b.fourier);  // Q8: (v, remapped_u)
     if (prob.is_mass) {
         f = bsdf_value;
         wi_out = local_to_world(b, wi);
@@ -353,7 +365,7 @@ PD void bsdf_sample_l(const Bsdf& b, f3 wo, float u, float v, f3& f, f3& wi_out,
     f3 other_f = gray(0.0f);
     for (uint32_t k = 0; k < others; ++k) {
         uint32_t idx = (k == chosen) ? (b.n - 1) : k;
-        ProbD p = bxdf_prob(b.lobe(idx), wo, wi, false);
+        ProbD p = bxdf_prob(b.lobe(idx), wo, wi, false, b.fourier);
         if (!p.is_mass) {
             count += 1;
             other_pdf_sum += p.v;
@@ -361,7 +373,7 @@ PD void bsdf_sample_l(const Bsdf& b, f3 wo, float u, float v, f3& f, f3& wi_out,
     }
     for (uint32_t k = 0; k < others; ++k) {
         uint32_t idx = (k == chosen) ? (b.n - 1) : k;
-        other_f = other_f + bxdf_eval(b.lobe(idx), b.albedo_at(idx), wo, wi, false);
+        other_f = other_f + bxdf_eval(b.lobe(idx), b.albedo_at(idx), wo, wi, false, b.fourier);
     }
     float overall_pdf = (prob.v + other_pdf_sum) / (float)(1 + count);
     f = bsdf_value + other_f;

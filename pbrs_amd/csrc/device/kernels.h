@@ -363,6 +363,9 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 #define PBRS_SHADE_LAMBERT 1u
 #define PBRS_SHADE_LIGHT_SPHERE 2u
 #define PBRS_SHADE_LIGHT_TRIANGLE 4u
+//   PBRS_SHADE_FOURIER        the other way round: some material is a Fourier BSDF (device/fourier.h), whose code only the
+//                             kernels with this bit contain (its f64 series sums and Newton loops are long and register-hungry)
+#define PBRS_SHADE_FOURIER 8u
 template <uint32_t INTEG, bool TEX, uint32_t SPEC>
 __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
                                               uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count, uint32_t sorted, const uint2* range) {
@@ -514,6 +517,8 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
 #endif
             Bsdf bs = bsdf_new_frame(is, S.bxdfs + mat->first_bxdf, mat->n_bxdfs);
             bs.lam = (SPEC & PBRS_SHADE_LAMBERT) != 0u;
+            const FourierView fourier_view{S.fourier, S.tex_floats, S.tex_words};
+            bs.fourier = (SPEC & PBRS_SHADE_FOURIER) ? &fourier_view : nullptr;
             if (TEX && (mat->flags & PBRS_MATERIAL_TEXTURED)) {
                 // `mtl.bxdfs_at(&hit)` with non-Solid textures (material/src/lib.rs:180-184, :317-365): evaluate each
                 // lobe's colour at (uv, pos) once, keep the lobes the material pushes for this hit

@@ -45,6 +45,7 @@ struct DevScene {
     const uint32_t* tex_words;
     uint32_t env_kind, env_texture;
     float env_scale[3];
+    const pbrs_fourier_table* fourier;  // geometry/src/fourier.rs tables (device/fourier.h); their arrays are in the texture pools
     // Shading classes: materials with the same lobe signature (kinds, Fresnel forms, textured or not) share one; the device
     // copy of an instance carries its material's class in pad[0].  More than one class with lobes: the bounce queues are
     // ordered by class before k_shade (kernels.h, k_class_sort).

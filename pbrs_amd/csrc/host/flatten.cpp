@@ -397,6 +397,13 @@ void flatten_material(const pbrs_material_spec& m, pbrs_material* out, std::vect
         case PBRS_MTL_SUBSTRATE:  // :393-420 — degenerates to Lambert (Q18)
             if (!(black3(p) && black3(p + 3))) bx.push_back(bx_lambert(p));
             break;
+        case PBRS_MTL_FOURIER: {  // :467-470: one FourierBSDF over the material's table
+            pbrs_bxdf b = bx_zero();
+            b.kind = PBRS_BXDF_FOURIER;
+            b.intrusion = m.tex[0];
+            bx.push_back(b);
+            break;
+        }
         default: break;
     }
     out->n_bxdfs = (uint32_t)bx.size() - out->first_bxdf;
@@ -433,6 +440,7 @@ struct pbrs_host_scene {
     std::vector<pbrs_texture> textures;
     std::vector<float> tex_floats;
     std::vector<uint32_t> tex_words;
+    std::vector<pbrs_fourier_table> fourier_tables;
     pbrs_scene_desc desc;
     pbrs_camera camera;
     uint32_t stack_depth;
@@ -641,8 +649,65 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
         g_error = "bad environment light";
         return PBRS_E_INVALID;
     }
+    // -- Fourier BSDF tables: FourierTable::build (geometry/src/fourier.rs:115-151) over the arrays of the file; what its
+    // asserts and slice bounds would stop is an error here
+    for (uint32_t t = 0; t < spec->n_fourier_tables; ++t) {
+        const pbrs_fourier_table_spec& fs = spec->fourier_tables[t];
+        const size_t n = fs.n_mu, nn = n * n;
+        if (n < 3 || n > 4096 || (fs.n_channels != 1 && fs.n_channels != 3) || !fs.mu || !fs.cdf || !fs.offset_and_length || (fs.n_coeffs && !fs.a)) {
+            g_error = "Fourier table: bad sizes or missing arrays";
+            return PBRS_E_INVALID;
+        }
+        for (size_t i = 0; i + 1 < n; ++i)
+            if (!(fs.mu[i] <= fs.mu[i + 1])) {
+                g_error = "Fourier table: mu is not ascending";  // :198-200
+                return PBRS_E_INVALID;
+            }
+        int32_t m_max = 0;
+        for (size_t i = 0; i < nn; ++i) {
+            const int32_t off = fs.offset_and_length[2 * i], len = fs.offset_and_length[2 * i + 1];
+            if (off < 0 || len < 0 || (uint64_t)off + (uint64_t)len * fs.n_channels > fs.n_coeffs) {
+                g_error = "Fourier table: a coefficient series lies outside the coefficient array";  // :127-130
+                return PBRS_E_INVALID;
+            }
+            m_max = len > m_max ? len : m_max;
+        }
+        pbrs_fourier_table ft{};
+        ft.n_mu = fs.n_mu;
+        ft.n_channels = fs.n_channels;
+        ft.m_max = (uint32_t)m_max;
+        ft.n_coeffs = fs.n_coeffs;
+        auto& F = hs->tex_floats;
+        auto& W = hs->tex_words;
+        if (F.size() + n + 2 * nn + fs.n_coeffs + (size_t)m_max > 0xffffffffull || W.size() + 2 * nn > 0xffffffffull) {
+            g_error = "Fourier table: texture pools exceed 2^32 entries";
+            return PBRS_E_INVALID;
+        }
+        ft.mu = (uint32_t)F.size();
+        F.insert(F.end(), fs.mu, fs.mu + n);
+        ft.cdf = (uint32_t)F.size();
+        F.insert(F.end(), fs.cdf, fs.cdf + nn);
+        ft.a0 = (uint32_t)F.size();
+        for (size_t i = 0; i < nn; ++i)  // :131-137
+            F.push_back(fs.offset_and_length[2 * i + 1] > 0 ? fs.a[fs.offset_and_length[2 * i]] : 0.0f);
+        ft.a = (uint32_t)F.size();
+        F.insert(F.end(), fs.a, fs.a + fs.n_coeffs);
+        ft.recip = (uint32_t)F.size();
+        for (int32_t i = 0; i < m_max; ++i) F.push_back(1.0f / (float)i);  // :138 (`(i as f32).recip()`; entry 0 is never read)
+        ft.a_offset = (uint32_t)W.size();
+        for (size_t i = 0; i < nn; ++i) W.push_back((uint32_t)fs.offset_and_length[2 * i]);
+        ft.m_lookup = (uint32_t)W.size();
+        for (size_t i = 0; i < nn; ++i) W.push_back((uint32_t)fs.offset_and_length[2 * i + 1]);
+        hs->fourier_tables.push_back(ft);
+    }
     // -- materials
     for (uint32_t m = 0; m < spec->n_materials; ++m) {
+        if (spec->materials[m].kind == PBRS_MTL_FOURIER) {
+            if (spec->materials[m].tex[0] >= spec->n_fourier_tables) {
+                g_error = "Fourier material references a missing table";
+                return PBRS_E_INVALID;
+            }
+        } else
         for (int k = 0; k < 4; ++k)
             if (spec->materials[m].tex[k] > spec->n_textures) {
                 g_error = "material references a missing texture";
@@ -655,7 +720,7 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
                                                        /* plastic */ 0,    /* Dielectric */ 4, /* DiffuseLight */ 3, /* uber */ 2,
                                                        /* substrate */ 1};
             const uint32_t kind = spec->materials[m].kind;
-            pm.vis_class = kind <= PBRS_MTL_SUBSTRATE ? palette_of_kind[kind] : 9u;
+            pm.vis_class = kind <= PBRS_MTL_SUBSTRATE ? palette_of_kind[kind] : kind == PBRS_MTL_FOURIER ? 6u : 9u;  // "Fourier" => 6
         }
         if (pm.n_bxdfs > PBRS_MAX_BXDFS) {
             g_error = "material with more than PBRS_MAX_BXDFS lobes";
@@ -782,6 +847,7 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
     d.n_textures = (uint32_t)hs->textures.size(); d.textures = hs->textures.data();
     d.n_tex_floats = (uint32_t)hs->tex_floats.size(); d.tex_floats = hs->tex_floats.data();
     d.n_tex_words = (uint32_t)hs->tex_words.size(); d.tex_words = hs->tex_words.data();
+    d.n_fourier_tables = (uint32_t)hs->fourier_tables.size(); d.fourier_tables = hs->fourier_tables.data();
     hs->stack_depth = troot.second + max_blas_height;
     *out = hs.release();
     return PBRS_OK;

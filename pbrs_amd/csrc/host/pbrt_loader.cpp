@@ -5,7 +5,7 @@
 // two binary formats it reads).  The output is the same plain-data scene the synthetic builders produce, so everything
 // downstream (flattener, kernels, oracle) is shared.  What the reference leaves `unimplemented!()` / `todo!()` / panicking
 // (object instancing, CoordinateSystem / Transform / ConcatTransform, spot and projection lights, spectrum / blackbody
-// colours, .spd files, Fourier materials, Loop subdivision, ASCII PLY) is reported as an error here instead of aborting.
+// colours, .spd files, Loop subdivision, ASCII PLY) is reported as an error here instead of aborting.
 // The reference holds no tests or scene files for this layer ("parity unpinned"); tests/test_pbrt_loader.py checks it
 // against scenes assembled directly through the spec.
 #include <zlib.h>
@@ -700,6 +700,49 @@ RawImage load_png(const std::string& path) {
 
 }  // namespace
 
+// ---- geometry/src/fourier.rs:55-96, :167-221: a `.bsdf` file (SCATFUN, version 1) ---------------------------------------
+struct RawBsdf {
+    std::vector<float> mu, cdf, a;
+    std::vector<int32_t> offset_and_length;
+    uint32_t n_channels = 0;
+    float eta = 1.0f;
+};
+static std::unique_ptr<RawBsdf> load_bsdf(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail("can't open the BSDF file " + path);
+    unsigned char h[64];
+    if (!f.read(reinterpret_cast<char*>(h), 64)) fail("BSDF file shorter than its header: " + path);
+    auto i32_at = [&](size_t at) {
+        int32_t v;
+        std::memcpy(&v, h + at, 4);
+        return v;
+    };
+    // read_header's asserts (:84-91): identifier, version 1, flags 1 (a BSDF, no harmonic extrapolation), finite eta / alpha
+    if (std::memcmp(h, "SCATFUN", 7) != 0 || h[7] != 1 || i32_at(8) != 1) fail("not a version-1 SCATFUN BSDF file: " + path);
+    const int32_t n_mu = i32_at(12), n_coeffs = i32_at(16), n_channels = i32_at(24);
+    float eta, alpha[2];
+    std::memcpy(&eta, h + 44, 4);
+    std::memcpy(alpha, h + 48, 8);
+    if (!std::isfinite(eta) || !std::isfinite(alpha[0]) || !std::isfinite(alpha[1])) fail("BSDF header holds a non-finite eta or alpha: " + path);
+    if (n_mu < 3 || n_mu > 4096 || n_coeffs < 0 || (n_channels != 1 && n_channels != 3)) fail("BSDF header sizes are out of range: " + path);
+    auto b = std::make_unique<RawBsdf>();
+    b->n_channels = (uint32_t)n_channels;
+    b->eta = eta;
+    const size_t nn = (size_t)n_mu * (size_t)n_mu;
+    b->mu.resize((size_t)n_mu);
+    b->cdf.resize(nn);
+    b->offset_and_length.resize(2 * nn);
+    b->a.resize((size_t)n_coeffs);
+    auto read_n = [&](void* dst, size_t bytes) {
+        if (bytes && !f.read(reinterpret_cast<char*>(dst), (std::streamsize)bytes)) fail("BSDF file is truncated: " + path);
+    };
+    read_n(b->mu.data(), 4 * b->mu.size());
+    read_n(b->cdf.data(), 4 * nn);
+    read_n(b->offset_and_length.data(), 8 * nn);
+    read_n(b->a.data(), 4 * b->a.size());
+    return b;
+}
+
 // ---- loader.rs -------------------------------------------------------------------------------------------------------
 struct pbrs_loaded_scene {
     pbrs_scene_spec spec{};
@@ -712,6 +755,8 @@ struct pbrs_loaded_scene {
     std::vector<pbrs_delta_light_spec> delta_lights;
     std::vector<pbrs_texture_spec> textures;
     std::vector<std::unique_ptr<RawImage>> images;
+    std::vector<pbrs_fourier_table_spec> fourier_tables;
+    std::vector<std::unique_ptr<RawBsdf>> bsdf_data;
     std::string filter;  // parsed, not used by this path
 };
 
@@ -853,8 +898,23 @@ struct Loader {
             m.kind = PBRS_MTL_SUBSTRATE;
             put3(m.p, color_param(ps, "Kd", gray(0.5f), "substrate"));
             put3(m.p + 3, color_param(ps, "Ks", gray(0.5f), "substrate"));
-        } else if (impl == "fourier") {
-            fail("fourier materials need .bsdf files and the Fourier BSDF, which are outside this path");
+        } else if (impl == "fourier") {  // :705-710, material::Fourier::from_file
+            std::string file;
+            if (!ps.lookup_string("string bsdffile", &file)) fail("string bsdffile");
+            out.bsdf_data.push_back(load_bsdf(root + "/" + file));
+            const RawBsdf& b = *out.bsdf_data.back();
+            pbrs_fourier_table_spec t{};
+            t.n_mu = (uint32_t)b.mu.size();
+            t.n_channels = b.n_channels;
+            t.n_coeffs = (uint32_t)b.a.size();
+            t.eta = b.eta;
+            t.mu = b.mu.data();
+            t.cdf = b.cdf.data();
+            t.offset_and_length = b.offset_and_length.data();
+            t.a = b.a.data();
+            m.kind = PBRS_MTL_FOURIER;
+            m.tex[0] = (uint32_t)out.fourier_tables.size();
+            out.fourier_tables.push_back(t);
         } else {
             fail("not recognized material: " + impl);
         }
@@ -1208,6 +1268,7 @@ int pbrs_host_load_pbrt(const char* path, pbrs_loaded_scene** out) {
         s.n_area_lights = (uint32_t)ls->area_lights.size(); s.area_lights = ls->area_lights.data();
         s.n_delta_lights = (uint32_t)ls->delta_lights.size(); s.delta_lights = ls->delta_lights.data();
         s.n_textures = (uint32_t)ls->textures.size(); s.textures = ls->textures.data();
+        s.n_fourier_tables = (uint32_t)ls->fourier_tables.size(); s.fourier_tables = ls->fourier_tables.data();
         if (s.n_instances == 0) fail("the scene has no shapes");
         *out = ls.release();
         return PBRS_OK;

@@ -64,6 +64,7 @@ struct pbrs_ctx {
     pbrs_stats pending{};
     bool pending_counters = false, pending_times = false;
     bool textured = false;  // the uploaded scene evaluates non-Solid textures: k_shade<.., true>
+    bool fourier = false;   // ... has a Fourier BSDF lobe: k_shade<.., true, PBRS_SHADE_FOURIER>
     uint32_t lambert_class = 0;    // shading class of the Lambert-only materials (0: none)
     uint32_t light_spec = 0;       // PBRS_SHADE_LIGHT_*: every area light has that shape
     bool split_lambert = true;     // PBRS_SPLIT_LAMBERT=0 in the environment: one general k_shade launch for all classes (A/B timing)
@@ -367,7 +368,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         const uint32_t sorted = (c->S.n_classes > 1u && rc.integrator <= PBRS_INTEGRATOR_DIRECT && c->sort_classes) ? 1u : 0u;
         // ... and where one of the classes is Lambertian (and the integrator has a Lambert variant), class-major over the whole
         // queue, so that the class gets a launch of that variant and the other classes one of the general kernel
-        const bool split = sorted && c->lambert_class && c->split_lambert && !c->textured && rc.integrator == PBRS_INTEGRATOR_PATH;
+        const bool split = sorted && c->lambert_class && c->split_lambert && !c->textured && !c->fourier && rc.integrator == PBRS_INTEGRATOR_PATH;
         const uint32_t n_tiles = (N + PBRS_SORT_TILE - 1) / PBRS_SORT_TILE;
         if (split) {
             hipLaunchKernelGGL(k_class_count, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
@@ -386,6 +387,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false, 0u);
             } else if (rc.integrator == PBRS_INTEGRATOR_NORMALS) {
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_NORMALS, false, 0u);
+            } else if (c->fourier) {  // some material is a Fourier BSDF: the kernels that carry the lobe (and textures)
+                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true, PBRS_SHADE_FOURIER);
+                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true, PBRS_SHADE_FOURIER);
             } else if (c->textured) {  // some material evaluates a non-Solid texture per hit
                 if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true, 0u);
                 else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true, 0u);
@@ -612,11 +616,30 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         if (m.vis_bxdf > d->n_bxdfs) return fail(c, PBRS_E_INVALID, "material visualiser record out of range");
         if (m.vis_bxdf == 0) vis_records = false;
     }
-    bool textured = false;
+    bool textured = false, fourier = false;
     for (uint32_t i = 0; i < d->n_bxdfs; ++i) {
         const uint32_t t = d->bxdfs[i].tex & ~PBRS_BXDF_TEX_DROP_IF_BLACK;
         if (t > d->n_textures) return fail(c, PBRS_E_INVALID, "lobe texture out of range");
         textured = textured || t != 0;
+        if (d->bxdfs[i].kind > PBRS_BXDF_FOURIER) return fail(c, PBRS_E_INVALID, "unknown lobe kind");
+        if (d->bxdfs[i].kind == PBRS_BXDF_FOURIER) {
+            if (d->bxdfs[i].intrusion >= d->n_fourier_tables) return fail(c, PBRS_E_INVALID, "Fourier lobe table out of range");
+            fourier = true;
+        }
+    }
+    // Fourier tables (geometry/src/fourier.rs:99-151): every array inside the pools, every series inside the coefficients,
+    // so that no lane can index outside them whatever the directions
+    for (uint32_t i = 0; i < d->n_fourier_tables; ++i) {
+        const pbrs_fourier_table& t = d->fourier_tables[i];
+        const uint64_t n = t.n_mu, nn = n * n, nf = d->n_tex_floats, nw = d->n_tex_words;
+        if (n < 3 || (t.n_channels != 1 && t.n_channels != 3)) return fail(c, PBRS_E_INVALID, "Fourier table: sizes");
+        if (t.mu + n > nf || t.cdf + nn > nf || t.a0 + nn > nf || (uint64_t)t.a + t.n_coeffs > nf || (uint64_t)t.recip + t.m_max > nf ||
+            t.a_offset + nn > nw || t.m_lookup + nn > nw)
+            return fail(c, PBRS_E_INVALID, "Fourier table: arrays out of range");
+        for (uint64_t k = 0; k < nn; ++k) {
+            const uint64_t off = d->tex_words[t.a_offset + k], len = d->tex_words[t.m_lookup + k];
+            if (len > t.m_max || off + len * t.n_channels > t.n_coeffs) return fail(c, PBRS_E_INVALID, "Fourier table: series out of range");
+        }
     }
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         const pbrs_texture& t = d->textures[i];
@@ -734,6 +757,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     if ((rc = upload(c, d->textures, d->n_textures, &S.textures))) return rc;
     if ((rc = upload(c, d->tex_floats, d->n_tex_floats, &S.tex_floats))) return rc;
     if ((rc = upload(c, d->tex_words, d->n_tex_words, &S.tex_words))) return rc;
+    if ((rc = upload(c, d->fourier_tables, d->n_fourier_tables, &S.fourier))) return rc;
     S.env_kind = d->env_kind;
     S.env_texture = d->env_texture;
     std::memcpy(S.env_scale, d->env_scale, sizeof S.env_scale);
@@ -800,6 +824,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     }
     c->S = S;
     c->textured = textured;
+    c->fourier = fourier;
     c->has_vis_records = vis_records;
     c->stack_depth = depth;
     c->has_scene = true;

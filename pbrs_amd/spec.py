@@ -11,7 +11,7 @@ import numpy as np
 
 SHAPE_SPHERE, SHAPE_QUAD, SHAPE_CUBOID, SHAPE_DISK, SHAPE_TRIANGLE, SHAPE_MESH = range(6)
 (MTL_LAMBERTIAN, MTL_METAL, MTL_GLOSSY, MTL_MIRROR, MTL_PLASTIC, MTL_DIELECTRIC, MTL_DIFFUSE_LIGHT, MTL_UBER,
- MTL_SUBSTRATE) = range(9)
+ MTL_SUBSTRATE, MTL_FOURIER) = range(10)
 MTL_FLAG_REMAP_ROUGHNESS, MTL_FLAG_HAS_KR, MTL_FLAG_HAS_KT = 1, 2, 4
 DELTA_POINT, DELTA_DISTANT = 0, 1
 TEX_CHECKER, TEX_PERLIN, TEX_IMAGE = 1, 2, 3
@@ -32,6 +32,12 @@ class MeshSpec(C.Structure):
 class TextureSpec(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("odd", C.c_float * 3), ("even", C.c_float * 3), ("freq", C.c_float),
                 ("width", C.c_uint32), ("height", C.c_uint32), ("data", C.POINTER(C.c_float)), ("perm", C.POINTER(C.c_uint32))]
+
+
+class FourierTableSpec(C.Structure):
+    _fields_ = [("n_mu", C.c_uint32), ("n_channels", C.c_uint32), ("n_coeffs", C.c_uint32), ("eta", C.c_float),
+                ("mu", C.POINTER(C.c_float)), ("cdf", C.POINTER(C.c_float)), ("offset_and_length", C.POINTER(C.c_int32)),
+                ("a", C.POINTER(C.c_float))]
 
 
 class MaterialSpec(C.Structure):
@@ -64,7 +70,8 @@ class SceneSpec(C.Structure):
                 ("n_delta_lights", C.c_uint32), ("delta_lights", C.POINTER(DeltaLightSpec)),
                 ("env_constant", C.c_float * 3), ("camera", CameraSpec),
                 ("n_textures", C.c_uint32), ("textures", C.POINTER(TextureSpec)),
-                ("env_kind", C.c_uint32), ("env_texture", C.c_uint32), ("env_scale", C.c_float * 3)]
+                ("env_kind", C.c_uint32), ("env_texture", C.c_uint32), ("env_scale", C.c_float * 3),
+                ("n_fourier_tables", C.c_uint32), ("fourier_tables", C.POINTER(FourierTableSpec))]
 
 
 # ---- AffineTransform (geometry/src/transform.rs:133-194) in f32, column-major Mat4 -----------------
@@ -145,6 +152,7 @@ class SceneBuilder:
         self.env = (0.0, 0.0, 0.0)
         self.env_kind, self.env_texture, self.env_scale = ENV_CONSTANT, 0, (1.0, 1.0, 1.0)
         self.textures = []  # (TextureSpec, arrays kept alive)
+        self.fourier_tables = []  # FourierTableSpec (arrays kept alive in _keep)
         self.camera = None
         self._keep = []
 
@@ -288,6 +296,29 @@ class SceneBuilder:
     def substrate(self, kd, ks):
         return self.material(MTL_SUBSTRATE, list(kd) + list(ks))
 
+    def fourier_table(self, table):
+        """Registers a pbrs_amd.fourier.FourierTable (the arrays of a `.bsdf` file, geometry/src/fourier.rs:167-221);
+        returns its index for fourier()."""
+        mu = np.ascontiguousarray(table.mu, dtype=f32)
+        cdf = np.ascontiguousarray(table.cdf, dtype=f32).reshape(-1)
+        ol = np.ascontiguousarray(table.offset_and_length, dtype=np.int32).reshape(-1)
+        a = np.ascontiguousarray(table.a, dtype=f32)
+        assert len(mu) >= 3 and len(cdf) == len(mu) ** 2 and len(ol) == 2 * len(mu) ** 2 and table.n_channels in (1, 3)
+        t = FourierTableSpec()
+        t.n_mu, t.n_channels, t.n_coeffs, t.eta = len(mu), table.n_channels, len(a), float(f32(table.eta))
+        t.mu, t.cdf = mu.ctypes.data_as(C.POINTER(C.c_float)), cdf.ctypes.data_as(C.POINTER(C.c_float))
+        t.offset_and_length = ol.ctypes.data_as(C.POINTER(C.c_int32))
+        t.a = a.ctypes.data_as(C.POINTER(C.c_float))
+        self._keep.extend([mu, cdf, ol, a])
+        self.fourier_tables.append(t)
+        return len(self.fourier_tables) - 1
+
+    def fourier(self, table_index):
+        """material::Fourier (material/src/lib.rs:451-475) over a registered table."""
+        m = self.material(MTL_FOURIER, [])
+        self.materials[m].tex[0] = int(table_index)
+        return m
+
     # -- instances / lights / camera
     def instance(self, shape, material, transform=None):
         """`shape` is a ShapeSpec (added) or an existing shape index."""
@@ -369,4 +400,5 @@ class SceneBuilder:
         spec.env_kind, spec.env_texture = self.env_kind, self.env_texture
         for i in range(3):
             spec.env_scale[i] = float(f32(self.env_scale[i]))
+        spec.n_fourier_tables, spec.fourier_tables = len(self.fourier_tables), arr(self.fourier_tables, FourierTableSpec)
         return spec

@@ -13,7 +13,8 @@ def test_every_reference_kat_is_transcribed():
     expected = {"local_trigonometry_test", "fresnel_test", "specular_refl_test", "diffuse_refl_test", "play_with_mf_brdf",
                 "diff_area_validate", "pdf_integral_validate", "beckmann_rho", "quad_frame_test", "custom_frame_test", "sphere_test",
                 "tricky_triangle", "reflect_refract_test", "float_doctests", "bbox_transform_test", "sphere_sample_pdf_integrate",
-                "observe_sphere_sample_towards", "lambertian_test", "mf_refl_test"}
+                "observe_sphere_sample_towards", "lambertian_test", "mf_refl_test", "find_interval_test", "catmull_test",
+                "fourier_sum_test"}
     assert expected <= set(NAMES)
 
 

@@ -202,7 +202,7 @@ WorldEnd
 @pytest.mark.parametrize("text,needle", [
     ('WorldBegin WorldEnd', "Camera"),
     ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin ObjectBegin "a" ObjectEnd WorldEnd', "instancing"),
-    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "fourier" WorldEnd', "fourier"),
+    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "fourier" WorldEnd', "bsdffile"),
     ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Shape "sphere" WorldEnd', "material"),
     ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Bogus WorldEnd', "token"),
     ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "matte" "blackbody Kd" [6500 1] Shape "sphere" WorldEnd', "spectral"),
