@@ -128,11 +128,6 @@ def test_random_scene_matches_oracle(gpu_ctx, seed):
         assert (img.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all(), (seed, integrator)
 
 
-def test_no_random_scene_was_skipped():
-    """The tie skip above must stay an exception: a change of scenes or seeds that starts skipping comparisons fails here."""
-    assert SKIPPED_FOR_TIES == [], SKIPPED_FOR_TIES
-
-
 def test_random_scenes_contain_parallel_quads():
     kinds = set()
     for seed in range(48):
@@ -166,3 +161,32 @@ def test_random_scene_rays_match_oracle(gpu_ctx, seed):
         assert (h_ref["inst"][keep] == h_gpu["inst"][keep]).all() and (h_ref["prim"][keep] == h_gpu["prim"][keep]).all(), seed
         assert (h_ref["b1"].view(np.uint32)[keep] == h_gpu["b1"].view(np.uint32)[keep]).all(), seed
         assert (occ_ref == occ_gpu).all(), seed
+
+
+@pytest.mark.parametrize("seed", range(0, 48, 4))
+def test_random_scene_with_fourier_materials_matches_oracle(gpu_ctx, seed):
+    """The randomised scenes again with two of their objects re-covered by Fourier BSDFs (geometry/src/fourier.rs; one- and
+    three-channel tables): the lobe's f64 series sums and Newton loops next to every other material, light and texture, in
+    the kernels that carry it (k_shade<.., true, PBRS_SHADE_FOURIER>)."""
+    import fourier_scenes
+    sb = random_scene(seed)
+    for k, name in ((1, "rgb"), (2, "mono")):
+        sb.instances[k].material = sb.fourier(sb.fourier_table(fourier_scenes.table(name)))
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    for integrator, depth in (("path", 7), ("direct", 3)):
+        ref, ost = osc.render(2, 2, depth, 3 + seed, integrator=integrator)
+        img, st = gpu_ctx.render(2, 2, depth, 3 + seed, integrator=integrator, counters=True)
+        if ost["tlas_ties"]:
+            SKIPPED_FOR_TIES.append((seed, integrator, "fourier"))
+            continue
+        assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"], (seed, integrator)
+        assert st["invalid_samples"] == ost["nonfinite_samples"], (seed, integrator)
+        nan = np.isnan(ref)
+        assert (nan == np.isnan(img)).all(), (seed, integrator)
+        assert (img.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all(), (seed, integrator)
+
+
+def test_no_random_scene_was_skipped():
+    """The tie skip above must stay an exception: a change of scenes or seeds that starts skipping comparisons fails here."""
+    assert SKIPPED_FOR_TIES == [], SKIPPED_FOR_TIES
