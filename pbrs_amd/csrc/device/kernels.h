@@ -53,6 +53,7 @@ struct RenderConst {
     uint32_t pass_first_sample;  // sample index of k = 0 in this pass
     uint32_t n_pixels;           // P
     uint32_t n_slots;            // P * K of this pass
+    uint32_t chunk_pixels;       // slot order of a pass (slot_of_sample): chunks of this many pixels, each with its K samples
     uint32_t band_rows, band_count, band_index;  // interleaved row bands (pbrs_render_params)
     uint32_t integrator;                         // PBRS_INTEGRATOR_*
     uint64_t seed;
@@ -69,11 +70,33 @@ PD float4 pack4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 PD f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
 #define PBRS_SLOT_MASK 0x3fffffffu
 
+// ---- slot order of a pass ----------------------------------------------------------------------------------------
+// The P * K camera samples of a pass, in queue order: the pixels are cut into chunks of C (RenderConst::chunk_pixels; the
+// last one shorter), and a chunk's samples come sample index by sample index — slot = chunk * C * K + k * C_chunk + pixel in
+// chunk.  A wave still holds 64 neighbouring pixels of one sample index, but the K samples of a chunk now follow each
+// other, and since a traversal kernel's blocks take the queue in eight contiguous segments, one per XCD (wave_fetch), an
+// XCD works through its own band of the image chunk by chunk: the BVH subtrees and triangles under a chunk are fetched
+// into that XCD's L2 once and serve all K samples, instead of once per sample index in all eight L2s (the order K, then
+// pixels, that a plain `slot = k * P + pixel` gives).  The radiance of a sample does not depend on its slot.
+PD void sample_of_slot(uint32_t slot, uint32_t n_pixels, uint32_t k_count, uint32_t chunk, uint32_t& k, uint32_t& pix) {
+    const uint32_t per_chunk = chunk * k_count;
+    const uint32_t c = slot / per_chunk, rem = slot - c * per_chunk, first = c * chunk;
+    const uint32_t size = n_pixels - first < chunk ? n_pixels - first : chunk;
+    k = rem / size;
+    pix = first + (rem - k * size);
+}
+PD uint32_t slot_of_sample(uint32_t k, uint32_t pix, uint32_t n_pixels, uint32_t k_count, uint32_t chunk) {
+    const uint32_t c = pix / chunk, first = c * chunk;
+    const uint32_t size = n_pixels - first < chunk ? n_pixels - first : chunk;
+    return c * chunk * k_count + k * size + (pix - first);
+}
+
 // ---- raygen --------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= rc.n_slots) return;
-    uint32_t k = slot / rc.n_pixels, pix = slot - k * rc.n_pixels;
+    uint32_t k, pix;
+    sample_of_slot(slot, rc.n_pixels, rc.n_slots / rc.n_pixels, rc.chunk_pixels, k, pix);
     uint32_t col = rc.x0 + pix % rc.w, vrow = pix / rc.w;
     uint32_t row = rc.y0 + (rc.band_count > 1 ? ((vrow / rc.band_rows) * rc.band_count + rc.band_index) * rc.band_rows + vrow % rc.band_rows : vrow);
     uint32_t i = rc.pass_first_sample + k;
@@ -993,13 +1016,13 @@ __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_
 // ---- accumulate / finalize -----------------------------------------------------------------------------------------
 // color_sum = color_sum + integrator(...) for strictly increasing sample index (src/main.rs:205)
 // Also counts the samples whose radiance is not finite (pbrs_stats.invalid_samples): one atomic per wave that saw any.
-__global__ void __launch_bounds__(256) k_accumulate(PathState st, float* sum, uint32_t n_pixels, uint32_t k_count, unsigned long long* nonfinite) {
+__global__ void __launch_bounds__(256) k_accumulate(PathState st, float* sum, uint32_t n_pixels, uint32_t k_count, uint32_t chunk, unsigned long long* nonfinite) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
     f3 s = mk3(sum[p], sum[n_pixels + p], sum[2 * n_pixels + p]);
     uint32_t bad = 0;
     for (uint32_t k = 0; k < k_count; ++k) {
-        uint32_t slot = k * n_pixels + p;
+        const uint32_t slot = slot_of_sample(k, p, n_pixels, k_count, chunk);
         const f3 l = xyz(st.L[slot]);
         bad += (pn_isfinite(l.x) && pn_isfinite(l.y) && pn_isfinite(l.z)) ? 0u : 1u;
         s = s + l;

@@ -244,6 +244,14 @@ RenderConst make_const(const pbrs_camera* cam, const pbrs_render_params* p) {
     rc.band_rows = p->band_rows; rc.band_count = p->band_count; rc.band_index = p->band_index;
     rc.seed = p->seed;
     rc.integrator = p->integrator;
+    // slot order of a pass (kernels.h, sample_of_slot): chunks of 4 K pixels, a multiple of the block and of the wave (C4:
+    // 1156 Msamples/s with the sample index outermost, 1208-1211 with chunks of 256 ... 16 K pixels, 1202 with 64 K)
+    rc.chunk_pixels = 4096u;
+    if (const char* e = getenv("PBRS_RAYGEN_CHUNK")) {  // developer override (A/B timing): 0 = sample index outermost, as in round 1
+        const long v = std::atol(e);
+        rc.chunk_pixels = v > 0 ? (uint32_t)v : 0xffffffffu;
+    }
+    if (rc.chunk_pixels > rc.n_pixels) rc.chunk_pixels = rc.n_pixels;  // one chunk: slot = k * P + pixel
     return rc;
 }
 
@@ -425,7 +433,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         tm.end();
     }
     if (tm.begin(4)) return fail(c, PBRS_E_DEVICE, "event record failed");
-    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, c->sum, P, kc, c->nonfinite);
+    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, c->sum, P, kc, rc.chunk_pixels, c->nonfinite);
     tm.end();
     HIPCHK(c, hipGetLastError());
     return PBRS_OK;

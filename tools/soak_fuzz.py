@@ -1,5 +1,6 @@
 """Developer tool (GPU box): the two randomised-scene parity tests of tests/test_gpu_fuzz.py over a range of seeds far
-beyond the ones the suite runs: images of both integrators and hit records / occlusion ray by ray, GPU vs oracle, bit for bit.
+beyond the ones the suite runs: images of both integrators (also with two objects re-covered by Fourier BSDFs) and hit
+records / occlusion ray by ray, GPU vs oracle, bit for bit.
 usage: python tools/soak_fuzz.py [first_seed [end_seed]]   (default 48 3000; about 40 seeds per second)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +17,7 @@ for seed in range(first, end):
     try:
         F.test_random_scene_rays_match_oracle(ctx, seed)
         F.test_random_scene_matches_oracle(ctx, seed)
+        F.test_random_scene_with_fourier_materials_matches_oracle(ctx, seed)
     except AssertionError as e:
         bad.append((seed, str(e)[:100]))
     if seed % 256 == 0:
