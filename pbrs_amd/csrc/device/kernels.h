@@ -54,6 +54,7 @@ struct RenderConst {
     uint32_t n_pixels;           // P
     uint32_t n_slots;            // P * K of this pass
     uint32_t chunk_pixels;       // slot order of a pass (slot_of_sample): chunks of this many pixels, each with its K samples
+    uint32_t tiles8_per_row;     // w / 8 when the pixels of the tile are taken in 8 x 8 blocks (pixel_of_order), else 0
     uint32_t band_rows, band_count, band_index;  // interleaved row bands (pbrs_render_params)
     uint32_t integrator;                         // PBRS_INTEGRATOR_*
     uint64_t seed;
@@ -91,12 +92,28 @@ PD uint32_t slot_of_sample(uint32_t k, uint32_t pix, uint32_t n_pixels, uint32_t
     return c * chunk * k_count + k * size + (pix - first);
 }
 
+// The order the pixels of the tile are taken in: 8 x 8 blocks, row-major over the blocks and inside a block, when the
+// tile's width and height are multiples of 8 (tiles8_per_row != 0) — a wave's 64 camera rays then leave through a square of
+// the film instead of a 64-pixel line, and walk the same nodes for longer — else row-major.  order <-> pixel (row-major):
+PD uint32_t pixel_of_order(uint32_t q, uint32_t w, uint32_t tiles8_per_row) {
+    if (tiles8_per_row == 0u) return q;
+    const uint32_t t = q >> 6, r = q & 63u;
+    const uint32_t ty = t / tiles8_per_row, tx = t - ty * tiles8_per_row;
+    return (ty * 8u + (r >> 3)) * w + tx * 8u + (r & 7u);
+}
+PD uint32_t order_of_pixel(uint32_t pix, uint32_t w, uint32_t tiles8_per_row) {
+    if (tiles8_per_row == 0u) return pix;
+    const uint32_t y = pix / w, x = pix - y * w;
+    return (((y >> 3) * tiles8_per_row + (x >> 3)) << 6) + ((y & 7u) << 3) + (x & 7u);
+}
+
 // ---- raygen --------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= rc.n_slots) return;
     uint32_t k, pix;
     sample_of_slot(slot, rc.n_pixels, rc.n_slots / rc.n_pixels, rc.chunk_pixels, k, pix);
+    pix = pixel_of_order(pix, rc.w, rc.tiles8_per_row);
     uint32_t col = rc.x0 + pix % rc.w, vrow = pix / rc.w;
     uint32_t row = rc.y0 + (rc.band_count > 1 ? ((vrow / rc.band_rows) * rc.band_count + rc.band_index) * rc.band_rows + vrow % rc.band_rows : vrow);
     uint32_t i = rc.pass_first_sample + k;
@@ -1016,13 +1033,14 @@ __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_
 // ---- accumulate / finalize -----------------------------------------------------------------------------------------
 // color_sum = color_sum + integrator(...) for strictly increasing sample index (src/main.rs:205)
 // Also counts the samples whose radiance is not finite (pbrs_stats.invalid_samples): one atomic per wave that saw any.
-__global__ void __launch_bounds__(256) k_accumulate(PathState st, float* sum, uint32_t n_pixels, uint32_t k_count, uint32_t chunk, unsigned long long* nonfinite) {
+__global__ void __launch_bounds__(256) k_accumulate(PathState st, float* sum, uint32_t n_pixels, uint32_t k_count, uint32_t chunk, uint32_t w,
+                                                     uint32_t tiles8_per_row, unsigned long long* nonfinite) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
     f3 s = mk3(sum[p], sum[n_pixels + p], sum[2 * n_pixels + p]);
     uint32_t bad = 0;
     for (uint32_t k = 0; k < k_count; ++k) {
-        const uint32_t slot = slot_of_sample(k, p, n_pixels, k_count, chunk);
+        const uint32_t slot = slot_of_sample(k, order_of_pixel(p, w, tiles8_per_row), n_pixels, k_count, chunk);
         const f3 l = xyz(st.L[slot]);
         bad += (pn_isfinite(l.x) && pn_isfinite(l.y) && pn_isfinite(l.z)) ? 0u : 1u;
         s = s + l;

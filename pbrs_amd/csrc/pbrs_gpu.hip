@@ -252,6 +252,10 @@ RenderConst make_const(const pbrs_camera* cam, const pbrs_render_params* p) {
         rc.chunk_pixels = v > 0 ? (uint32_t)v : 0xffffffffu;
     }
     if (rc.chunk_pixels > rc.n_pixels) rc.chunk_pixels = rc.n_pixels;  // one chunk: slot = k * P + pixel
+    rc.tiles8_per_row = (p->w % 8u == 0u && p->h % 8u == 0u) ? p->w / 8u : 0u;
+    if (const char* e = getenv("PBRS_RAYGEN_TILES8")) {  // developer override (A/B timing)
+        if (std::atoi(e) == 0) rc.tiles8_per_row = 0u;
+    }
     return rc;
 }
 
@@ -433,7 +437,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         tm.end();
     }
     if (tm.begin(4)) return fail(c, PBRS_E_DEVICE, "event record failed");
-    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, c->sum, P, kc, rc.chunk_pixels, c->nonfinite);
+    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, c->sum, P, kc, rc.chunk_pixels, rc.w, rc.tiles8_per_row, c->nonfinite);
     tm.end();
     HIPCHK(c, hipGetLastError());
     return PBRS_OK;
@@ -939,6 +943,7 @@ int pbrs_camera_rays(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_para
     rc = ensure_work(c, P, P);
     if (rc) return rc;
     RenderConst k = make_const(cam, p);
+    k.tiles8_per_row = 0u;  // one sample index, exported by pixel: slot = pixel
     k.pass_first_sample = sample_index;
     k.n_slots = P;
     hipLaunchKernelGGL(k_raygen, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, k);
@@ -987,6 +992,7 @@ int pbrs_render_sample_radiance(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_
     rc = ensure_work(c, P, P);
     if (rc) return rc;
     RenderConst k = make_const(cam, p);
+    k.tiles8_per_row = 0u;  // one sample index, exported by pixel: slot = pixel
     Timer tm{c, false};
     HIPCHK(c, hipMemsetAsync(c->sum, 0, 3 * (size_t)P * sizeof(float), c->stream));
     rc = run_pass(c, k, sample_index, 1, false, tm);
