@@ -240,10 +240,14 @@ class Workload:
                 "queue_state_bytes_per_launch": dom["queue_state_bytes_per_launch"], "scene_miss_bytes_per_launch": dom["scene_miss_bytes_per_launch"],
                 "scene_bytes_per_launch": dom["scene_bytes_per_launch"], "cache_work_rate_GBps": dom["cache_work_rate_GBps"],
                 "ms_per_launch": dom["ms_per_launch"], "launches_per_step": dom["launches"],
+                "valu_issue_frac": dom.get("valu_issue_frac"), "valu_lanes_active": dom.get("valu_lanes_active"),
                 "note": "rank 0's kernels, the stage with the most time per frame; achieved = (queue/state bytes that must cross HBM, SURVEY.md §8d "
                         "per-unit figures x units of one launch, + scene bytes that missed the caches) / HIP-event time per launch; scene misses "
                         "and traffic = HBM bytes per launch from separate rocprofv3 TCC passes, measured offline, see profiles/; "
-                        "cache_work_rate prices every node / triangle visit at record size and is NOT an HBM figure",
+                        "cache_work_rate prices every node / triangle visit at record size and is NOT an HBM figure; valu_issue_frac = "
+                        "share of the chip's vector issue slots the kernel fills (wave-level VALU instructions per launch from the SQ "
+                        "pass in profiles/, x 4 cycles, over 1024 SIMDs x the live kernel time x 2.4 GHz): where it is near 1 the kernel "
+                        "is bound by instruction issue, not by HBM",
             },
             "traversal": trav,
             "stages_ms_per_step": times,

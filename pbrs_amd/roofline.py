@@ -23,6 +23,9 @@ the full feature set; what the lean variants skip (tri_shading fetches of shadin
 """
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
 L2_BYTES_PER_XCD = 4 << 20
+N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs (same guide)
+CLOCK_HZ = 2.4e9        # peak engine clock (same guide); the sustained clock is lower, so issue fractions are lower bounds
+CYCLES_PER_WAVE_VALU = 4  # a wave64 vector instruction occupies its 16-lane SIMD for 4 cycles
 
 B_CLOSEST_RAY = 52    # queue read (o 12, d 12, t_max 4, path id 4) + hit write (t, inst, prim, b1, b2 = 20)
 B_SHADOW_RAY = 68     # queue read 32 + pending contribution 12 + radiance r/w 24
@@ -94,6 +97,23 @@ def kernel_traffic(traffic_doc, kernel, stage_launches_per_frame=None):
     return total / n
 
 
+def kernel_valu(traffic_doc, kernel, stage_launches_per_frame=None):
+    """(wave-level vector instructions per stage launch, mean active lanes) of the uninstrumented instantiation(s) of
+    `kernel` in a traffic document that carries the SQ pass (tools/traffic_from_pmc.py), or None."""
+    if not traffic_doc:
+        return None
+    rows = [v for k, v in traffic_doc.get("kernels", {}).items()
+            if (k == kernel or (k.startswith(kernel + "<") and not k.startswith(kernel + "<true"))) and "valu_insts" in v]
+    n = sum(v["launches"] for v in rows)
+    if not n:
+        return None
+    total = sum(v["valu_insts"] * v["launches"] for v in rows)
+    lanes = sum(v["valu_insts"] * v["launches"] * v.get("valu_lanes_active", 0.0) for v in rows) / total if total else 0.0
+    frames = traffic_doc.get("geometry", {}).get("frames")
+    per_launch = total / (frames * stage_launches_per_frame) if stage_launches_per_frame and frames else total / n
+    return per_launch, lanes
+
+
 def stage_report(counters, times, scene_nbytes=0, traffic_doc=None):
     """counters: stats dict of an instrumented frame; times: per-frame stage times and launch counts of the timed frames;
     scene_nbytes: size of the resident scene; traffic_doc: parsed profiles/latest_traffic_<config>.json or None."""
@@ -124,6 +144,13 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None):
             "cache_work_rate_GBps": ((q + sc) / sec / 1e9) if sec > 0 else 0.0,  # not an HBM figure: may exceed the HBM peak
         }
         out[stage]["frac"] = out[stage]["achieved_GBps"] / HBM_PEAK_GBS
+        valu = kernel_valu(traffic_doc, kernel, launches)
+        if valu and sec > 0:
+            # share of the chip's vector issue slots the kernel fills (instruction counts measured offline, time live): what
+            # binds the kernels that HBM does not — a lower bound, the sustained clock being below CLOCK_HZ
+            out[stage]["valu_insts_per_launch"] = valu[0]
+            out[stage]["valu_lanes_active"] = valu[1]
+            out[stage]["valu_issue_frac"] = valu[0] * CYCLES_PER_WAVE_VALU / (N_SIMD * sec * CLOCK_HZ)
     return out
 
 

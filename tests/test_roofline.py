@@ -48,3 +48,16 @@ def test_fractions_are_fractions_of_the_hbm_peak():
     t = roofline.traversal(rep)
     assert t["frac"] == t["achieved"] / roofline.HBM_PEAK_GBS and t["cache_work_rate_GBps"] >= t["achieved"]
     assert roofline.dominant(rep)[0] == "extend"
+
+
+def test_vector_issue_share_from_the_sq_pass():
+    """A kernel HBM does not bind: wave-level VALU instructions per launch (offline SQ pass) x 4 cycles over the chip's SIMD
+    cycles in the live kernel time."""
+    doc = {"geometry": {"frames": 1}, "kernels": {"k_extend<false, 13u>": {"launches": 2, "hbm_total": 1.0, "valu_insts": 1.2e6, "valu_lanes_active": 40.0},
+                                                    "k_extend<true, 15u>": {"launches": 1, "hbm_total": 1.0, "valu_insts": 9e9, "valu_lanes_active": 1.0},
+                                                    "k_shade<0u, false, 3u>": {"launches": 2, "hbm_total": 1.0}}}
+    rep = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30, traffic_doc=doc)
+    e = rep["extend"]
+    assert e["valu_insts_per_launch"] == 1.2e6 and e["valu_lanes_active"] == 40.0
+    assert e["valu_issue_frac"] == 1.2e6 * 4 / (1024 * 1.0e-3 * 2.4e9)  # 2.0 ms over 2 launches
+    assert "valu_issue_frac" not in rep["shade"] and "valu_issue_frac" not in rep["shadow"]  # no SQ figures: not reported

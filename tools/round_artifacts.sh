@@ -34,7 +34,7 @@ for cfg in $cfgs; do
     grep '^{"config"' $out/pmc_${n}_$cfg.log > $out/geometry_$cfg.json
     rm -rf $out/pmc_tmp
   done
-  python3 $R/tools/traffic_from_pmc.py $out/geometry_$cfg.json $out/pmc_1_fetch_size_$cfg.txt $out/pmc_2_write_size_$cfg.txt $out/pmc_3_tcc_ea0_rdreq_sum_$cfg.txt $out/pmc_4_tcc_ea0_wrreq_sum_$cfg.txt > $out/traffic_$cfg.json || exit 1
+  python3 $R/tools/traffic_from_pmc.py $out/geometry_$cfg.json $out/pmc_1_fetch_size_$cfg.txt $out/pmc_2_write_size_$cfg.txt $out/pmc_3_tcc_ea0_rdreq_sum_$cfg.txt $out/pmc_4_tcc_ea0_wrreq_sum_$cfg.txt $out/pmc_5_sq_wave_cycles_$cfg.txt > $out/traffic_$cfg.json || exit 1
 done
 echo "== plain default bench"; date +%T
 cd $R && timeout -k 10 600 python3 bench.py > $out/bench.log 2>&1; grep '^{"metric"' $out/bench.log > $out/bench.json

@@ -1,6 +1,6 @@
 """Turns rocprofv3 TCC counter passes (tools/pmc_summary.py outputs) into HBM traffic per launch per kernel.
 
-    python tools/traffic_from_pmc.py GEOMETRY.json fetch.txt write.txt [rdreq_sizes.txt [wrreq.txt]]
+    python tools/traffic_from_pmc.py GEOMETRY.json fetch.txt write.txt [rdreq_sizes.txt [wrreq.txt [sq_wave_cycles.txt]]]
 
 Units and gfx950 corrections as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are in
 KiB and come from the L2's memory-side request counters (Infinity-Cache hits are counted, not excluded); on gfx950
@@ -9,7 +9,9 @@ doubling is calibrated on k_accumulate (a pure coalesced stream of known size) a
 other access widths uncalibrated, the optional third pass gives an independent figure for every kernel from the
 request-size counters of gfx950 (TCC_EA0_RDREQ_{32B,64B,128B}): read bytes = 32 n32 + 64 n64 + 128 n128, with requests
 of no recorded size counted at 64 B — reported as hbm_read_by_request_size next to hbm_read; bench.py uses the larger of
-the two so that a roofline fraction is never flattered.
+the two so that a roofline fraction is never flattered.  The optional sixth file (the SQ pass) adds, per kernel, the vector
+instructions of a launch and the lanes active in them: what bench.py turns into the share of the chip's vector issue slots a
+kernel uses (a wave64 instruction occupies a 16-lane SIMD for 4 cycles) — the bound of the kernels HBM does not bind.
 """
 import json
 import re
@@ -33,6 +35,7 @@ geo = json.load(open(sys.argv[1]))
 fetch, write = parse(sys.argv[2]), parse(sys.argv[3])
 sizes = parse(sys.argv[4]) if len(sys.argv) > 4 else {}
 wr = parse(sys.argv[5]) if len(sys.argv) > 5 else {}
+sq = parse(sys.argv[6]) if len(sys.argv) > 6 else {}
 n_pixels = geo["pixels"]
 n_slots = n_pixels * geo["samples_per_pass"]
 res = {"unit": "bytes per launch", "geometry": geo, "kernels": {}}
@@ -60,6 +63,12 @@ for k in fetch:
         hit, miss = s.get("TCC_HIT_sum"), s.get("TCC_MISS_sum")
         if hit is not None and miss is not None and hit + miss > 0:
             row["l2_hit_rate"] = hit / (hit + miss)
+    if k in sq and sq[k].get("SQ_INSTS_VALU"):
+        q, dq = sq[k], sq[k]["dispatches"]
+        row["valu_insts"] = q["SQ_INSTS_VALU"] / dq  # wave-level vector instructions per launch
+        row["valu_lanes_active"] = q.get("SQ_THREAD_CYCLES_VALU", 0.0) / q["SQ_INSTS_VALU"]  # of 64
+        if q.get("SQ_WAVE_CYCLES"):
+            row["wave_wait_share"] = q.get("SQ_WAIT_INST_ANY", 0.0) / q["SQ_WAVE_CYCLES"]  # of a wave's cycles spent waiting on an instruction's operands
     row["hbm_total"] = rd + wb
     res["kernels"][k] = row
 print(json.dumps(res, indent=1))
