@@ -413,6 +413,23 @@ def test_tiles_passes_and_bands_do_not_change_the_image(gpu_ctx):
         assert (bits(tiling.assemble(shares, 64, 48, world)) == bits(full)).all()
 
 
+@pytest.mark.parametrize("w,h", [(104, 72), (100, 70), (128, 64)])
+def test_slot_order_of_a_pass_does_not_change_the_image(gpu_ctx, w, h):
+    """Pass slots go by chunks of 4 096 pixels (each with its K samples) over 8 x 8 pixel blocks when the tile's sides are
+    multiples of 8 (kernels.h, sample_of_slot / pixel_of_order): more than one chunk with a shorter last one, sides that are
+    and are not multiples of 8, passes of uneven size — the image is the oracle's bit for bit, whatever the slot order."""
+    sb, c = scenes.build_config("c2", width=w, height=h)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    ref, ost = OracleScene(sb).render(3, 3, 5, 7)
+    for spp_pass in (0, 4, 9):
+        img, st = gpu_ctx.render(3, 3, 5, 7, samples_per_pass=spp_pass, counters=True)
+        assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+        assert (bits(img) == bits(ref)).all(), (w, h, spp_pass)
+    tile = (8, 8, w - 16, h - 8)  # an offset tile of the same film
+    img, _ = gpu_ctx.render(3, 3, 5, 7, tile=tile)
+    assert (bits(img) == bits(ref[8:, 8:w - 8])).all()
+
+
 def test_api_errors(gpu_ctx):
     sb, _ = golden_case("c1_sphere_light")
     gpu_ctx.upload(pbrs_amd.HostScene(sb))
