@@ -236,6 +236,20 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
         const uint64_t pm = __ballot(cond);                                                                    \
         if (pm && (threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)pm) - 1)) cnt.c.field++;       \
     } while (0)
+#ifdef PBRS_PROBE_UTIL2  /* lanes per mode at the start of a round, summed by the wave's first lane */
+#define PBRS_PROBE_UTIL_COUNT(walk, cnt)                                                          \
+    do {                                                                                          \
+        if (STATS && (threadIdx.x & 63u) == 0) {                                                  \
+            cnt.c.quads += 1;                                                                     \
+        }                                                                                         \
+        if (STATS) {                                                                              \
+            const uint32_t pn_ = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_NODE));      \
+            const uint32_t pl_ = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));      \
+            const uint32_t px_ = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_XFER));      \
+            if ((threadIdx.x & 63u) == 0) cnt.c.cuboids += pn_, cnt.c.disks += pl_, cnt.c.tri_shading += px_; \
+        }                                                                                         \
+    } while (0)
+#else
 #define PBRS_PROBE_UTIL_COUNT(walk, cnt)                                                          \
     do {                                                                                          \
         if (STATS) {                                                                              \
@@ -243,14 +257,21 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
             PBRS_PROBE_ONE(true, quads);                                                          \
         }                                                                                         \
     } while (0)
+#endif
 #define PBRS_PROBE_XFER_COUNT(cnt)                               \
     do {                                                         \
         if (STATS) PBRS_PROBE_ONE(true, spheres); /* wave-level boundary-step executions */ \
     } while (0)
+#ifdef PBRS_PROBE_UTIL2
+#define PBRS_PROBE_LEAF_COUNT(cnt) \
+    do {                           \
+    } while (0)
+#else
 #define PBRS_PROBE_LEAF_COUNT(cnt)                               \
     do {                                                         \
         if (STATS) PBRS_PROBE_ONE(true, disks); /* wave-level leaf-step executions */ \
     } while (0)
+#endif
 #else
 #define PBRS_PROBE_UTIL_COUNT(walk, cnt) \
     do {                                 \
