@@ -365,6 +365,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
         if ((uint32_t)__popcll(live) < S.refill_below) {
             if (walk.mode == PBRS_WALK_DONE) {  // finished walks are retired in batches, at refill time
+                walk.finish(cnt);  // a walk that ended inside an instance: its candidate meets the best hit here
                 const Hit& h = walk.best;
                 nhit += h.inst != 0xffffffffu ? 1u : 0u;
                 // k_shade rebuilds the Interaction from (t, inst, prim): the barycentrics are recomputed there, as the

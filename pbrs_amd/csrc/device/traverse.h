@@ -317,8 +317,8 @@ struct ClosestWalk {
 
     // One node: pop, box test, then push the children / hold the leaf / stop at the instance boundary.
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
-        if (in_blas && sp == blas_base) {  // the instance's entries are used up: leave it (xfer_step)
-            mode = PBRS_WALK_XFER;
+        if (in_blas && sp == blas_base) {  // the instance's entries are used up: leave it (xfer_step, or finish at retire time)
+            mode = exit_mode();
             return;
         }
         // One box test serves lanes at a BLAS / TLAS node and lanes whose turn it is to test a scanned leaf of a small TLAS
@@ -340,7 +340,7 @@ struct ClosestWalk {
         }
         const pbrs_node node = load_node(S.nodes + ni);
         if (!slab_rs(node, C, lt)) {
-            if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = PBRS_WALK_XFER;
+            if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = exit_mode();
             return;
         }
         if (!(node.b & PBRS_LEAF_FLAG)) {
@@ -366,24 +366,42 @@ struct ClosestWalk {
     // Instance boundary, both directions.  Any one lane crosses a boundary in few of its steps, but some lane of a wave
     // does in nearly every round; inline, this code (ray transform, reciprocals, scratch traffic) ran for a handful of
     // lanes each round.  As a state of its own the kernel runs it when enough lanes wait at a boundary (k_extend).
+    // The instance's candidate meets the best hit so far (bvh.rs:82-95 after Instance::intersect returned)
+    PD void meet_best(Cnt<STATS>& cnt) {
+        // a mesh candidate always has t < inf (it beat outer_hit.ray_t = inf); an analytic one may sit at t == +inf
+        // (x / 0 with an infinite extent), so those are flagged
+        if (mt < pn_inf() || (inst_info & 0x80000000u)) {
+            CNT(instance_hits);
+            if (!(best.t < mt)) {
+                best.t = mt;
+                best.inst = cur_inst;
+                best.prim = mprim;
+                best.b1 = mb1;
+                best.b2 = mb2;
+                t_max = mt;
+            }
+        }
+    }
+    // Where a lane goes when the instance it is in has nothing left: to the boundary step — unless nothing is left above
+    // it either (no pending TLAS entry, no scanned leaf still to visit).  Then the walk is over: the world-space ray is
+    // not needed again, and the candidate meets `best` when the lane is retired (finish), together with the other lanes
+    // of the batch instead of in a boundary step of its own (one of the ≈2.3 such steps a C4 ray takes).
+    PD uint32_t exit_mode() const {
+        const bool nothing_above = blas_base == 0 && (!(FEAT & PBRS_FEAT_FLAT_TLAS) || cand == 0u);
+        return nothing_above ? PBRS_WALK_DONE : PBRS_WALK_XFER;
+    }
+    PD void finish(Cnt<STATS>& cnt) {  // at retire time, every lane whose walk is DONE
+        if (in_blas) {
+            in_blas = false;
+            meet_best(cnt);
+        }
+    }
     PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
         mode = PBRS_WALK_NODE;
         if (in_blas) {  // intersect_bvh / the shape returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
             in_blas = false;
             leave_instance(S, stk, !moved ? PBRS_SPACE_WORLD : (inst_info & 0x40000000u) ? PBRS_SPACE_TRANSLATED : PBRS_SPACE_MOVED, C);
-            // a mesh candidate always has t < inf (it beat outer_hit.ray_t = inf); an analytic one may sit at t == +inf
-            // (x / 0 with an infinite extent), so those are flagged
-            if (mt < pn_inf() || (inst_info & 0x80000000u)) {
-                CNT(instance_hits);
-                if (!(best.t < mt)) {
-                    best.t = mt;
-                    best.inst = cur_inst;
-                    best.prim = mprim;
-                    best.b1 = mb1;
-                    best.b2 = mb2;
-                    t_max = mt;
-                }
-            }
+            meet_best(cnt);
             lt = t_max;  // back in the TLAS
             return;
         }
@@ -417,7 +435,7 @@ struct ClosestWalk {
     // The analytic shape of a TLAS leaf (per lane; triangles go through leaf_wave).
     PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
         const uint32_t kind = inst_info & 7u;
-        mode = PBRS_WALK_XFER;  // the shape was all there is below this TLAS leaf: straight to the way out
+        mode = exit_mode();  // the shape was all there is below this TLAS leaf: straight to the way out
         if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
         // an analytic shape in its own space (C), extent = the TLAS extent at entry (lt)
         const float* p = S.shapes[leaf_a].p;
@@ -573,9 +591,14 @@ struct AnyWalk {
             mode = PBRS_WALK_NODE;
         }
     }
+    // see ClosestWalk::exit_mode; an unoccluded ray has nothing to carry out of the instance
+    PD uint32_t exit_mode() const {
+        const bool nothing_above = blas_base == 0 && (!(FEAT & PBRS_FEAT_FLAT_TLAS) || cand == 0u);
+        return nothing_above ? PBRS_WALK_DONE : PBRS_WALK_XFER;
+    }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
         if (in_blas && sp == blas_base) {
-            mode = PBRS_WALK_XFER;
+            mode = exit_mode();
             return;
         }
         if (sp == 0) {  // not inside an instance (its exit was taken above), nothing pending: the next scanned leaf, or the end
@@ -598,7 +621,7 @@ struct AnyWalk {
             else CNT(tlas_nodes);
         }
         if (!slab_rs(node, C, t_max)) {
-            if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = PBRS_WALK_XFER;
+            if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = exit_mode();
             return;
         }
         if (!(node.b & PBRS_LEAF_FLAG)) {
@@ -683,7 +706,7 @@ struct AnyWalk {
     PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
         bool hit;
         {
-            mode = PBRS_WALK_XFER;  // straight to the way out of the instance
+            mode = exit_mode();  // straight to the way out of the instance
             if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
             const float* p = S.shapes[leaf_a].p;
             switch (inst_kind) {
@@ -728,6 +751,7 @@ PD void tlas_closest(const DevScene& S, bool active, f3 o, f3 d, float t_max, La
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
         if (__ballot(w.mode == PBRS_WALK_LEAF)) w.leaf_wave(S, cnt);
     }
+    w.finish(cnt);
     best = w.best;
 }
 template <bool STATS>
