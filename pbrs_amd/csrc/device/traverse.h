@@ -411,6 +411,10 @@ struct ClosestWalk {
         const pbrs_instance& in = S.inst[cur_inst];
         CNT(instances);
         const uint32_t kind = inst_info;
+        if ((FEAT & PBRS_FEAT_ANALYTIC) && kind != PBRS_SHAPE_MESH && kind != PBRS_SHAPE_TRIANGLE) {
+            analytic_visit(S, in, kind, cnt);  // back at the TLAS already
+            return;
+        }
         const uint32_t space = enter_instance(S, in, C, kind == PBRS_SHAPE_MESH, stk);
         moved = space != PBRS_SPACE_WORLD;
         in_blas = true;
@@ -426,62 +430,58 @@ struct ClosestWalk {
             leaf_a = in.blas_root;
             leaf_end = in.blas_root + 1u;
             mode = PBRS_WALK_LEAF;
-        } else if (FEAT & PBRS_FEAT_ANALYTIC) {
-            leaf_a = in.shape_index;
-            mode = PBRS_WALK_LEAF;
         }
     }
 
-    // The analytic shape of a TLAS leaf (per lane; triangles go through leaf_wave).
-    PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
-        const uint32_t kind = inst_info & 7u;
-        mode = exit_mode();  // the shape was all there is below this TLAS leaf: straight to the way out
+    // Instance::intersect (instance.rs:50-67) for an analytic shape, which is all there is below its TLAS leaf, in one go:
+    // the ray into the shape's space (literal products, as the reference makes them), the shape's test against the TLAS
+    // extent, the candidate against the best hit (bvh.rs:82-95).  The lane's space stays the world's: no way in, no way
+    // out, no wait for the primitive step in between (round 1 and most of round 2: three states, three waits).
+    PD void analytic_visit(const DevScene& S, const pbrs_instance& in, uint32_t kind, Cnt<STATS>& cnt) {
         if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
-        // an analytic shape in its own space (C), extent = the TLAS extent at entry (lt)
-        const float* p = S.shapes[leaf_a].p;
+        const f3 o = xf_apply(in.inv, C.o, 1.0f), d = xf_apply(in.inv, C.d, 0.0f);
+        const float ext = t_max;  // the TLAS extent at entry
+        const float* p = S.shapes[in.shape_index].p;
         float t = 0.0f, b1 = 0.0f, b2 = 0.0f;
         bool hit = false;
         switch (kind) {
             case PBRS_SHAPE_SPHERE:
                 CNT(spheres);
-                hit = sphere_hit_t(ld3(p), p[3], C.o, C.d, lt, t);
+                hit = sphere_hit_t(ld3(p), p[3], o, d, ext, t);
                 break;
             case PBRS_SHAPE_QUAD: {
                 CNT(quads);
                 float u, v;
                 f3 n;
-                hit = quad_hit(ld3(p), ld3(p + 3), ld3(p + 6), C.o, C.d, lt, t, u, v, n);
+                hit = quad_hit(ld3(p), ld3(p + 3), ld3(p + 6), o, d, ext, t, u, v, n);
                 break;
             }
             case PBRS_SHAPE_CUBOID: {
                 CNT(cuboids);
                 int axis;
                 float bound;
-                hit = cuboid_hit(ld3(p), ld3(p + 3), C.o, C.d, lt, t, axis, bound);
+                hit = cuboid_hit(ld3(p), ld3(p + 3), o, d, ext, t, axis, bound);
                 break;
             }
             case PBRS_SHAPE_DISK:
                 CNT(disks);
-                hit = disk_hit_t(ld3(p), ld3(p + 3), ld3(p + 6), C.o, C.d, lt, t);
+                hit = disk_hit_t(ld3(p), ld3(p + 3), ld3(p + 6), o, d, ext, t);
                 break;
             default:  // PBRS_SHAPE_TRIANGLE never gets here (triangle-record path above)
                 break;
         }
-        if (hit) {
-            inst_info |= 0x80000000u;
-            mt = t;
-            mprim = 0;
-            mb1 = b1;
-            mb2 = b2;
-        }
+        inst_info = kind | (hit ? 0x80000000u : 0u);
+        mt = hit ? t : pn_inf();
+        mprim = 0;
+        mb1 = b1;
+        mb2 = b2;
+        meet_best(cnt);
+        lt = t_max;
     }
 
     // The held leaves of the whole wave in one execution (TriShare); every lane of the wave calls this together.
     PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
-        const uint32_t kind = inst_info & 7u;
-        const bool tri_leaf =
-            mode == PBRS_WALK_LEAF && (!(FEAT & PBRS_FEAT_ANALYTIC) || kind == PBRS_SHAPE_MESH || kind == PBRS_SHAPE_TRIANGLE);
-        if ((FEAT & PBRS_FEAT_ANALYTIC) && mode == PBRS_WALK_LEAF && !tri_leaf) analytic_leaf(S, cnt);
+        const bool tri_leaf = mode == PBRS_WALK_LEAF;  // analytic shapes never wait here (analytic_visit)
         TriShare sh;
         sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
         if (sh.has[0] == 0) return;
@@ -531,7 +531,7 @@ struct ClosestWalk {
         if (__ballot(win != 0xffffffffu)) {
             const float b1 = sh.from_helper(win, rb1), b2 = sh.from_helper(win, rb2);
             if (win != 0xffffffffu) {
-                mprim = kind == PBRS_SHAPE_MESH ? win_tri : 0u;
+                mprim = (inst_info & 7u) == PBRS_SHAPE_MESH ? win_tri : 0u;
                 mb1 = b1;
                 mb2 = b2;
             }
@@ -649,6 +649,10 @@ struct AnyWalk {
         }
         const pbrs_instance& in = S.inst[leaf_a];
         CNT(instances);
+        if ((FEAT & PBRS_FEAT_ANALYTIC) && inst_kind != PBRS_SHAPE_MESH && inst_kind != PBRS_SHAPE_TRIANGLE) {
+            analytic_visit(S, in, cnt);  // Instance::occludes in one go; back at the TLAS, or occluded
+            return;
+        }
         const uint32_t space = enter_instance(S, in, C, inst_kind == PBRS_SHAPE_MESH, stk);
         moved = space != PBRS_SPACE_WORLD;
         in_blas = true;
@@ -660,17 +664,12 @@ struct AnyWalk {
             leaf_a = in.blas_root;
             leaf_end = in.blas_root + 1u;
             mode = PBRS_WALK_LEAF;
-        } else if (FEAT & PBRS_FEAT_ANALYTIC) {
-            leaf_a = in.shape_index;
-            mode = PBRS_WALK_LEAF;
         }
     }
     // The held leaves of the whole wave in one execution (TriShare); every lane of the wave calls this together.
     // `intersect_bvh_pred` stops at a leaf's first occluder (blas.rs:478-495): the owner counts its triangles up to that one.
     PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
-        const bool tri_leaf = mode == PBRS_WALK_LEAF &&
-                              (!(FEAT & PBRS_FEAT_ANALYTIC) || (inst_kind & 7u) == PBRS_SHAPE_MESH || inst_kind == PBRS_SHAPE_TRIANGLE);
-        if ((FEAT & PBRS_FEAT_ANALYTIC) && mode == PBRS_WALK_LEAF && !tri_leaf) analytic_leaf(S, cnt);
+        const bool tri_leaf = mode == PBRS_WALK_LEAF;  // analytic shapes never wait here (analytic_visit)
         TriShare sh;
         sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
         if (sh.has[0] == 0) return;
@@ -702,29 +701,30 @@ struct AnyWalk {
             }
         }
     }
-    // The analytic shape of a TLAS leaf (per lane); an occluder ends the walk (mode DONE, occluded set).
-    PD void analytic_leaf(const DevScene& S, Cnt<STATS>& cnt) {
+    // Instance::occludes (instance.rs:68-72) for an analytic shape in one go, see ClosestWalk::analytic_visit; an occluder
+    // ends the walk (mode DONE, occluded set).
+    PD void analytic_visit(const DevScene& S, const pbrs_instance& in, Cnt<STATS>& cnt) {
         bool hit;
         {
-            mode = exit_mode();  // straight to the way out of the instance
             if (!(FEAT & PBRS_FEAT_ANALYTIC)) return;
-            const float* p = S.shapes[leaf_a].p;
+            const f3 o = xf_apply(in.inv, C.o, 1.0f), d = xf_apply(in.inv, C.d, 0.0f);
+            const float* p = S.shapes[in.shape_index].p;
             switch (inst_kind) {
                 case PBRS_SHAPE_SPHERE:
                     CNT(spheres);
-                    hit = sphere_occludes(ld3(p), p[3], C.o, C.d, t_max);
+                    hit = sphere_occludes(ld3(p), p[3], o, d, t_max);
                     break;
                 case PBRS_SHAPE_QUAD:
                     CNT(quads);
-                    hit = quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), C.o, C.d, t_max);
+                    hit = quad_occludes(ld3(p), ld3(p + 3), ld3(p + 6), o, d, t_max);
                     break;
                 case PBRS_SHAPE_CUBOID:  // Q14: the bbox slab test
                     CNT(cuboids);
-                    hit = slab_test(ld3(p), ld3(p + 3), C.o, C.d, t_max);
+                    hit = slab_test(ld3(p), ld3(p + 3), o, d, t_max);
                     break;
                 case PBRS_SHAPE_DISK:
                     CNT(disks);
-                    hit = disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), C.o, C.d);
+                    hit = disk_occludes(ld3(p), ld3(p + 3), ld3(p + 6), o, d);
                     break;
                 default:  // PBRS_SHAPE_TRIANGLE never gets here
                     hit = false;
