@@ -122,7 +122,7 @@ PD uint32_t enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace&
     f3 od = xf_apply(in.inv, C.d, 0.0f);
     if (need_slab) {
         C = make_space(oo, od, S.fast_slab != 0);
-    } else {  // an analytic shape: no boxes below the instance, the reciprocals are never read
+    } else {  // an IsolatedTriangle: no boxes below the instance, the reciprocals are never read
         C.o = oo;
         C.d = od;
         C.fast = false;
@@ -269,7 +269,7 @@ struct ClosestWalk {
     uint32_t mprim, cur_inst;
     uint32_t inst_info;  // of the instance the lane is in: shape kind | mesh flags << 3 | bit 30: entered by translating the origin only
                          // | bit 31: an analytic candidate is held
-    uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or leaf_a = the analytic shape
+    uint32_t leaf_a, leaf_end;  // held leaf: triangles [leaf_a, leaf_end) of a BLAS leaf, or the record of an IsolatedTriangle
     int sp, blas_base;
     uint32_t cand;        // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, moved;  // moved: C is not the world ray (inst_info bit 30: only its origin differs)
@@ -406,8 +406,9 @@ struct ClosestWalk {
             return;
         }
         // Instance::intersect (instance.rs:50-67): the ray goes into the instance's space and stays there until the
-        // walk is back at this stack level.  A mesh continues in the node state with its BLAS root; an analytic
-        // shape is one held primitive.  Either way the candidate (mt, ...) meets `best` at the exit above.
+        // walk is back at this stack level.  A mesh continues in the node state with its BLAS root, an IsolatedTriangle
+        // is one held triangle record; either way the candidate (mt, ...) meets `best` at the exit above (or at retire
+        // time, finish).  An analytic shape is visited here and now (analytic_visit).
         const pbrs_instance& in = S.inst[cur_inst];
         CNT(instances);
         const uint32_t kind = inst_info;
