@@ -1035,8 +1035,11 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_SHADOW_WAVES) k_shadow(D
 // visibility: Ld terms in the reference's order (directlighting.rs:193, :219), * n_lights (:98), * beta
 // (pathintegrator.rs:35).
 __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_t* queue, const uint32_t* count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count[0]) return;  // low half of the packed (nee paths, shadow rays) counter
+  const uint32_t n = count[0];  // low half of the packed (nee paths, shadow rays) counter
+  // A capped grid in strides (pbrs_gpu.hip, kStreamGridCap): the number of two-ray estimates is only known on the device — a
+  // few % of a bounce's vertices — and a grid sized for the whole pass costs 0.17 ms per launch in blocks that find nothing
+  // to do (an empty block is dispatched in ≈0.2 ns): 7 ms per frame of C4.
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     uint32_t slot = queue[i];
     // only area-light estimates cast two rays: Ld = term 1 (light sample, :193) + term 2 (BSDF sample, :219)
     bool occ0 = at(st.occ[0], slot) != 0, occ1 = at(st.occ[1], slot) != 0;
@@ -1050,6 +1053,7 @@ __global__ void __launch_bounds__(256) k_nee_resolve(PathState st, const uint32_
     f3 L = xyz(rl);
     L = L + cmul(nb, one * n0.w) * n1.w;  // the post factor is 1 for the path integrator: x * 1 == x bit for bit
     st.L[slot] = pack4(L, rl.w);
+  }
 }
 
 // ---- accumulate / finalize -----------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kMaxDepth = 64;
 constexpr uint32_t kHeadWords = PBRS_WORK_HEADS * PBRS_WORK_HEAD_STRIDE;
 constexpr uint32_t kCounterWords = (3 + 2 * kHeadWords) * (kMaxDepth + 2);  // act, ns (u64), then the work heads
+constexpr uint32_t kStreamGridCap = 4096;  // blocks of k_nee_resolve, whose work is counted on the device (kernels.h)
 constexpr uint32_t kPersistentBlocks = PBRS_PERSISTENT_BLOCKS;  // 256 CUs x up to 6 resident 256-thread blocks (VGPR/LDS permitting)
 constexpr size_t kLdsBytesPerCU = 160 * 1024;
 
@@ -349,6 +350,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     rc.pass_first_sample = first;
     rc.n_slots = N;
     const uint32_t grid = (N + kBlock - 1) / kBlock;
+    const uint32_t sgrid = grid < kStreamGridCap ? grid : kStreamGridCap;
     // persistent traversal kernels: enough blocks to fill the chip, each pulls work until the queue is empty
     const uint32_t pgrid = grid < kPersistentBlocks ? grid : kPersistentBlocks;
     const uint32_t stride = kMaxDepth + 2;
@@ -433,7 +435,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
         launch_shadow(c, stats, pgrid, lds, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords);
-        hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
+        hipLaunchKernelGGL(k_nee_resolve, dim3(sgrid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
         tm.end();
     }
     if (tm.begin(4)) return fail(c, PBRS_E_DEVICE, "event record failed");
