@@ -26,6 +26,7 @@ struct PathState {
     //   q[.][2][i] = beta.xyz,   RNG state, high word
     float4* q[2][3];
     float4* hit;  // [i] = t, inst (0xffffffff: miss), prim, shading class   written by k_extend at the ray's queue position
+    uint8_t* cls;     // [queue position] shading class of the hit, a byte beside hit[].w for the class sort's two passes
     uint32_t* perm;  // scenes with several shading classes: k_shade's lane j shades the path at queue position perm[j] (k_class_sort)
     // class-major order (scenes whose Lambertian class gets the Lambert variant of k_shade): per tile and class, the count
     // and then the offset inside the class; per class (and, at [PBRS_MAX_CLASSES], for all classes but the Lambertian) the
@@ -43,7 +44,7 @@ struct PathState {
     float4* nee[3];   // [slot]: c1.xyz, 1 / light_pdf | c2.xyz, post factor | beta at the time of the estimate, -
     uint8_t* occ[2];  // [slot], written by k_shadow: 1 = the ray is occluded
 };
-#define PBRS_STATE_BYTES_PER_PATH (2u * 48u + 16u + 4u + 16u + 2u * 48u + 48u + 2u + 4u)  // records above + the nee queue entry
+#define PBRS_STATE_BYTES_PER_PATH (2u * 48u + 16u + 4u + 1u + 16u + 2u * 48u + 48u + 2u + 4u)  // records above + the nee queue entry
 
 struct RenderConst {
     pbrs_camera cam;
@@ -373,6 +374,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
                 // the 4th word names the hit's shading class (pbrs_upload_scene: DevScene::inst_class), 0 for a miss
                 const uint32_t cls = (S.n_classes > 1u && h.inst != 0xffffffffu) ? S.inst[h.inst].pad[0] : 0u;
                 st.hit[item] = make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), __uint_as_float(cls));
+                if (S.n_classes > 1u) st.cls[item] = (uint8_t)cls;  // what the class sort reads: 1 byte per path instead of a 16-byte record
                 walk.mode = PBRS_WALK_IDLE;
             }
             if (work.left()) {
@@ -864,7 +866,7 @@ __global__ void __launch_bounds__(256) k_class_sort(PathState st, const uint32_t
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] = 0u;
     __syncthreads();
-    for (uint32_t i = base + threadIdx.x; i < end; i += 256u) atomicAdd(&s_tot[__float_as_uint(st.hit[i].w) & (PBRS_MAX_CLASSES - 1u)], 1u);
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256u) atomicAdd(&s_tot[(uint32_t)st.cls[i] & (PBRS_MAX_CLASSES - 1u)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {  // exclusive prefix over the classes
         uint32_t run = base;
@@ -878,7 +880,7 @@ __global__ void __launch_bounds__(256) k_class_sort(PathState st, const uint32_t
     for (uint32_t it = base; it < end; it += 256u) {  // every thread of the block takes part in the barriers
         const uint32_t i = it + threadIdx.x;
         const bool valid = i < end;
-        const uint32_t cls = valid ? (__float_as_uint(st.hit[i].w) & (PBRS_MAX_CLASSES - 1u)) : 0xffffffffu;
+        const uint32_t cls = valid ? ((uint32_t)st.cls[i] & (PBRS_MAX_CLASSES - 1u)) : 0xffffffffu;
         uint32_t rank = 0;
         for (uint32_t c = 0; c < PBRS_MAX_CLASSES; ++c) {
             const uint64_t m = __ballot(cls == c);
@@ -909,7 +911,7 @@ __global__ void __launch_bounds__(256) k_class_count(PathState st, const uint32_
     __shared__ uint32_t s_tot[PBRS_MAX_CLASSES];
     if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] = 0u;
     __syncthreads();
-    for (uint32_t i = base + threadIdx.x; i < end; i += 256u) atomicAdd(&s_tot[__float_as_uint(st.hit[i].w) & (PBRS_MAX_CLASSES - 1u)], 1u);
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256u) atomicAdd(&s_tot[(uint32_t)st.cls[i] & (PBRS_MAX_CLASSES - 1u)], 1u);
     __syncthreads();
     if (threadIdx.x < PBRS_MAX_CLASSES) st.tile_hist[blockIdx.x * PBRS_MAX_CLASSES + threadIdx.x] = s_tot[threadIdx.x];
 }
@@ -957,7 +959,7 @@ __global__ void __launch_bounds__(256) k_class_scatter(PathState st, const uint3
     for (uint32_t it = base; it < end; it += 256u) {  // every thread of the block takes part in the barriers
         const uint32_t i = it + threadIdx.x;
         const bool valid = i < end;
-        const uint32_t cls = valid ? (__float_as_uint(st.hit[i].w) & (PBRS_MAX_CLASSES - 1u)) : 0xffffffffu;
+        const uint32_t cls = valid ? ((uint32_t)st.cls[i] & (PBRS_MAX_CLASSES - 1u)) : 0xffffffffu;
         uint32_t rank = 0;
         for (uint32_t c = 0; c < PBRS_MAX_CLASSES; ++c) {
             const uint64_t m = __ballot(cls == c);

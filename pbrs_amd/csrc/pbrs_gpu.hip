@@ -140,7 +140,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         // q[2][3], hit, L, nee[3]: one float4 per path each; sr[3]: two per path; occ: two bytes; nee queue: one word
         const size_t n_tiles = n_slots / PBRS_SORT_TILE + 1;
         const size_t sort_bytes = align(n_tiles * PBRS_MAX_CLASSES * sizeof(uint32_t)) + align((PBRS_MAX_CLASSES + 1) * sizeof(uint2));
-        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + 2 * align(n_slots * sizeof(uint32_t)) + sort_bytes;
+        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + 2 * align(n_slots * sizeof(uint32_t)) + sort_bytes + align(n_slots);
         hipError_t e = hipMalloc(&c->state_mem, total);
         if (e != hipSuccess) {
             c->state_mem = nullptr;
@@ -161,6 +161,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         s.occ[1] = s.occ[0] + n_slots;
         c->neeq = reinterpret_cast<uint32_t*>(take(align(n_slots * sizeof(uint32_t))));
         s.perm = reinterpret_cast<uint32_t*>(take(align(n_slots * sizeof(uint32_t))));
+        s.cls = reinterpret_cast<uint8_t*>(take(align(n_slots)));
         s.tile_hist = reinterpret_cast<uint32_t*>(take(align(n_tiles * PBRS_MAX_CLASSES * sizeof(uint32_t))));
         s.class_range = reinterpret_cast<uint2*>(take(align((PBRS_MAX_CLASSES + 1) * sizeof(uint2))));
         c->st = s;
