@@ -10,7 +10,10 @@ and it is the same workload for every N so that the N = 1 value of a scaling run
 A step is one whole frame: every rank renders its interleaved row bands of the frame on its own GPU (scene already
 resident in HBM), copies them to the host and rank 0 assembles the frame (shared-memory frame, or a gloo gather; no RCCL:
 pixels are independent).  Total work is fixed as N grows, so scaling is reported as "strong".
-At N = 1 the same run also times C2 and C3 at full size (fewer steps) and reports them under `other_configs`.
+At N = 1 the same run also times C2 and C3 at full size and C5 on a stated 64-spp slice (fewer steps) and reports them under
+`other_configs`.  After the timed loop — outside the timed region, like the `cpu_baseline` leg — the oracle renders a 64 x 8
+window of the LAST TIMED FRAME at the workload's full strata and the line carries `parity_window` (bit-exact or not, max
+per-pixel L2 error); a failed window makes the process exit non-zero after the line is printed.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -27,6 +30,10 @@ import numpy as np  # noqa: E402
 
 DEFAULT_CONFIG = "c4"
 CPU_SAMPLES = {"c1": (256, 256, 4), "c2": (512, 512, 4), "c3": (512, 512, 4), "c4": (960, 540, 4), "c5": (960, 540, 4)}
+# the window of the timed frame the oracle re-renders (x0, y0, w, h), chosen where each scene has its mixed materials / deep BLAS
+PARITY_WINDOWS = {"c1": (96, 120, 64, 8), "c2": (480, 500, 64, 8), "c3": (300, 700, 64, 8), "c4": (900, 600, 64, 8), "c5": (1800, 1400, 64, 8)}
+# configs timed on a stated slice of their spp when they ride along in `other_configs` (samples are i.i.d. passes: SURVEY.md §8d)
+ALSO_STRATA = {"c5": (8, 8)}
 
 
 def parse():
@@ -35,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=DEFAULT_CONFIG, help="c1..c5 (BASELINE.json configs[0..4]); default c4 = the north-star workload")
-    ap.add_argument("--also", default=None, help="comma-separated configs timed after the main one at N = 1 (default: c2,c3 when --config is c4)")
+    ap.add_argument("--also", default=None, help="comma-separated configs timed after the main one at N = 1 (default: c2,c3,c5 when --config is c4; c5 on a 64-spp slice)")
     ap.add_argument("--also-steps", type=int, default=2)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -46,6 +53,7 @@ def parse():
     ap.add_argument("--integrator", default="path", choices=["path", "direct"],
                     help="path = src/pathintegrator.rs (the BASELINE metric); direct = direct_lighting_integrator (src/directlighting.rs:14-47)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-window", action="store_true", help="skip the oracle's window of the timed frame (developer A/B runs)")
     ap.add_argument("--cpu-sample", type=int, nargs=3, default=None, metavar=("W", "H", "MSAA"), help="CPU baseline sample (default per config)")
     ap.add_argument("--allow-shared-gpus", action="store_true",
                     help="rehearsal only: let more ranks than visible GPUs share devices round-robin (the JSON then says so)")
@@ -88,6 +96,28 @@ def cpu_baseline(config_name, depth, seed, sample, integrator="path"):
     }
 
 
+def parity_window(config_name, frame, window, sx, sy, depth, seed, integrator="path"):
+    """The oracle's render of `window` of the film at the workload's own strata against the same pixels of `frame` (a frame the
+    GPU produced in the timed loop).  The oracle is the checker here, never the thing measured."""
+    from oracle.binding import OracleScene
+    from pbrs_amd import scenes
+    H, W = frame.shape[:2]
+    x0, y0, w, h = window
+    x0, y0 = min(x0, max(W - w, 0)), min(y0, max(H - h, 0))
+    w, h = min(w, W), min(h, H)
+    sb, _ = scenes.build_config(config_name, width=W, height=H)
+    t = time.perf_counter()
+    ref, ost = OracleScene(sb).render(sx, sy, depth, seed, tile=(x0, y0, w, h), nthreads=host_cores(), integrator=integrator)
+    dt = time.perf_counter() - t
+    got = np.ascontiguousarray(frame[y0:y0 + h, x0:x0 + w])
+    nan = np.isnan(ref)
+    exact = bool((nan == np.isnan(got)).all() and (got.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all())
+    l2 = np.sqrt(((np.nan_to_num(got).astype(np.float64) - np.nan_to_num(ref).astype(np.float64)) ** 2).sum(axis=-1))
+    return {"rect": [x0, y0, w, h], "spp": sx * sy, "strata": [sx, sy], "samples": int(ost["samples"]), "bit_exact": exact,
+            "max_l2": float(l2.max()), "tolerance_l2": 1e-4, "oracle_panics": int(ost["panics"]), "oracle_s": dt,
+            "frame": "the last frame of the timed loop", "window_mean_radiance": [float(x) for x in ref.reshape(-1, 3).mean(axis=0)]}
+
+
 def device_identity(torch, ordinal):
     p = torch.cuda.get_device_properties(ordinal)
     ident = {"ordinal": ordinal, "name": p.name}
@@ -100,14 +130,14 @@ def device_identity(torch, ordinal):
 class Workload:
     """One BASELINE config resident on this rank's GPU, rendered frame by frame."""
 
-    def __init__(self, args, config, ctx, torch, dist, dev, world, rank):
+    def __init__(self, args, config, ctx, torch, dist, dev, world, rank, strata=None):
         import pbrs_amd
         from pbrs_amd import scenes, tiling
         self.args, self.name, self.ctx, self.torch, self.dist, self.world, self.rank = args, config, ctx, torch, dist, world, rank
         self.tiling = tiling
         sb, cfg = scenes.build_config(config, width=args.width, height=args.height)
-        if args.strata:
-            cfg["strata_x"], cfg["strata_y"] = args.strata
+        if strata or args.strata:
+            cfg["strata_x"], cfg["strata_y"] = strata or args.strata
         if args.depth:
             cfg["depth"] = args.depth
         self.W, self.H, self.sx, self.sy, self.depth = cfg["width"], cfg["height"], cfg["strata_x"], cfg["strata_y"], cfg["depth"]
@@ -169,7 +199,8 @@ class Workload:
         self.gather_s = 0.0
         t0 = time.perf_counter()
         stage_ms, launches = None, None
-        _, per_frame = self.frames(steps, timing=True)
+        timed_frame, per_frame = self.frames(steps, timing=True)
+
         for st in per_frame:
             if st is not None:
                 if stage_ms is None:
@@ -181,6 +212,8 @@ class Workload:
                     launches[k] += st[k]
         self.barrier()
         elapsed = time.perf_counter() - t0
+        if timed_frame is not None:
+            timed_frame = np.array(timed_frame, copy=True)  # after the clock has stopped: the host buffers are reused by the frames that follow
         gather_ms = self.gather_s / steps * 1e3
         if world > 1:
             t = torch.tensor([elapsed, gather_ms], dtype=torch.float64)
@@ -189,13 +222,18 @@ class Workload:
 
         # Untimed: instrumented frame for ray / node / primitive counts (deterministic, equal to the timed work).
         frame, (cst,) = self.frames(1, counters=True)
-        counts = np.array([cst["closest_rays"], cst["shadow_rays"], cst["samples"], cst["invalid_samples"]] if cst else [0, 0, 0, 0], dtype=np.float64)
+        nb = 16
+        counts = np.array(([cst["closest_rays"], cst["shadow_rays"], cst["samples"], cst["invalid_samples"], cst["shade_events"]] +
+                           list(cst["paths_at_bounce"]) + list(cst["shadow_rays_at_bounce"])) if cst else [0] * (5 + 2 * nb), dtype=np.float64)
         if world > 1:
             tc = torch.from_numpy(counts)
             dist.all_reduce(tc, op=dist.ReduceOp.SUM)
             counts = tc.numpy()
         if rank != 0:
             return None
+        # the instrumented frame is the same frame from other kernel instantiations: it must be the timed one bit for bit
+        frames_agree = bool((np.isnan(frame) == np.isnan(timed_frame)).all() and
+                            (frame.view(np.uint32)[~np.isnan(frame)] == timed_frame.view(np.uint32)[~np.isnan(timed_frame)]).all())
 
         W, H, sx, sy, depth, spp = self.W, self.H, self.sx, self.sy, self.depth, self.sx * self.sy
         samples_per_step = float(W) * H * spp
@@ -214,11 +252,22 @@ class Workload:
             # per-launch figures only carry over when a launch is the same size: same number of passes per frame
             if traffic_doc.get("geometry", {}).get("passes") not in (None, cst["passes"]):
                 traffic_doc, traffic_src = None, f"{traffic_src} ignored: measured at {traffic_doc['geometry']['passes']} passes per frame, this run has {cst['passes']}"
+            # ... and when the counters were measured on the kernels being timed: the file carries a hash of the sources
+            elif traffic_doc.get("source_hash") != roofline.source_hash():
+                traffic_doc, traffic_src = None, (f"{traffic_src} ignored: measured on sources {traffic_doc.get('source_hash')} "
+                                                  f"(git {traffic_doc.get('git_head')}), this run is built from {roofline.source_hash()}")
         rep = roofline.stage_report(cst, times, scene_nbytes=self.hs.nbytes, traffic_doc=traffic_doc)
         dom_name, dom = roofline.dominant(rep)
         trav = roofline.traversal(rep)
-        for r in list(rep.values()) + [trav]:
-            assert r["frac"] <= 1.0, f"roofline fraction above 1: {r}"  # a figure above the HBM peak is not an HBM figure
+        # the queue/state bytes are a model: a fraction above 1 says the model is off, which the line reports instead of hiding
+        inconsistent = [r["kernel"] if "kernel" in r else r["kernels"] for r in list(rep.values()) + [trav] if r["frac"] > 1.0]
+        window = None
+        if not self.args.no_parity_window:
+            window = parity_window(self.name, timed_frame, PARITY_WINDOWS[self.name], sx, sy, depth, self.args.seed, self.args.integrator)
+            window["timed_frame_equals_instrumented_frame"] = frames_agree
+        n_b = [float(x) for x in counts[5:5 + nb]]
+        s_b = [float(x) for x in counts[5 + nb:5 + 2 * nb]]
+        last = max([i for i, x in enumerate(n_b) if x > 0] + [0])
         return {
             "value": samples_per_step * steps / elapsed / 1e6,
             "unit": "Msamples/s",
@@ -230,20 +279,33 @@ class Workload:
                        "integrator": self.args.integrator, "scene_bytes_in_hbm": self.hs.nbytes, "full_size": self.full_size},
             "mrays_per_s": rays_per_step * steps / elapsed / 1e6,
             "rays_per_step": rays_per_step,
+            "closest_rays_per_step": counts[0],
+            "shadow_rays_per_step": counts[1],
+            "shade_events_per_step": counts[4],
+            # path vertices per camera sample (`scene.tlas.intersect` calls of src/pathintegrator.rs:16 per sample, misses included)
+            "mean_path_length": counts[0] / samples_per_step,
+            "rays_per_sample": rays_per_step / samples_per_step,
+            "paths_at_bounce": n_b[:last + 1],          # k_extend's queue, bounce by bounce, summed over the frame's passes
+            "shadow_rays_at_bounce": s_b[:last + 1],    # k_shadow's queue
             "invalid_samples": counts[3],
-            "frame_mean_radiance": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)],
+            "frame_mean_radiance": [float(x) for x in timed_frame.reshape(-1, 3).mean(axis=0)],
+            "parity_window": window,
             "gather_ms": gather_ms,
+            "roofline_inconsistent": inconsistent or False,
             "roofline": {
-                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["frac"], "traffic": dom["traffic_bytes_per_launch"], "traffic_source": traffic_src,
+                "bound": roofline.bound_of(dom), "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["frac"], "frac_measured": dom["frac_measured"], "traffic": dom["traffic_bytes_per_launch"], "traffic_source": traffic_src,
                 "bytes_per_launch": dom["queue_state_bytes_per_launch"] + dom["scene_miss_bytes_per_launch"],
                 "queue_state_bytes_per_launch": dom["queue_state_bytes_per_launch"], "scene_miss_bytes_per_launch": dom["scene_miss_bytes_per_launch"],
                 "scene_bytes_per_launch": dom["scene_bytes_per_launch"], "cache_work_rate_GBps": dom["cache_work_rate_GBps"],
                 "ms_per_launch": dom["ms_per_launch"], "launches_per_step": dom["launches"],
                 "valu_issue_frac": dom.get("valu_issue_frac"), "valu_lanes_active": dom.get("valu_lanes_active"),
-                "note": "rank 0's kernels, the stage with the most time per frame; achieved = (queue/state bytes that must cross HBM, SURVEY.md §8d "
-                        "per-unit figures x units of one launch, + scene bytes that missed the caches) / HIP-event time per launch; scene misses "
-                        "and traffic = HBM bytes per launch from separate rocprofv3 TCC passes, measured offline, see profiles/; "
+                "note": "rank 0's kernels, the stage with the most time per frame; bound = valu_issue when the kernel fills a larger share of the "
+                        "chip's vector issue slots than of the HBM peak (frac stays the HBM fraction); achieved = (queue/state bytes that must "
+                        "cross HBM: record sizes of the kernels' layout x units of one launch, pbrs_amd/roofline.py, + scene bytes that missed the "
+                        "caches) / HIP-event time per launch; frac_measured = traffic / time / peak; scene misses and traffic = L2 -> fabric bytes "
+                        "per launch from separate rocprofv3 TCC passes (Infinity-Cache hits included: an upper bound of HBM bytes), measured "
+                        "offline on the same sources (source hash checked), see profiles/; "
                         "cache_work_rate prices every node / triangle visit at record size and is NOT an HBM figure; valu_issue_frac = "
                         "share of the chip's vector issue slots the kernel fills (wave-level VALU instructions per launch from the SQ "
                         "pass in profiles/, x 4 cycles, over 1024 SIMDs x the live kernel time x 2.4 GHz): where it is near 1 the kernel "
@@ -269,6 +331,7 @@ def main():
     import torch.distributed as dist
 
     import pbrs_amd
+    from pbrs_amd import scenes as scenes_mod
 
     gpus_visible = torch.cuda.device_count()
     if gpus_visible == 0:
@@ -295,13 +358,19 @@ def main():
     main_wl.close()
 
     others = {}
-    also = args.also if args.also is not None else ("c2,c3" if args.config == DEFAULT_CONFIG and not (args.width or args.height or args.strata or args.depth) else "")
+    also = args.also if args.also is not None else ("c2,c3,c5" if args.config == DEFAULT_CONFIG and not (args.width or args.height or args.strata or args.depth) else "")
     if world == 1:
         for name in [c for c in also.split(",") if c]:
-            wl = Workload(args, name, ctx, torch, dist, dev, world, rank)
+            wl = Workload(args, name, ctx, torch, dist, dev, world, rank, strata=ALSO_STRATA.get(name))
             r = wl.measure(args.also_steps, 1)
             wl.close()
-            others[name] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "mrays_per_s", "config", "roofline", "traversal", "stages_ms_per_step")}
+            others[name] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "mrays_per_s", "mean_path_length", "config", "parity_window",
+                                              "roofline", "traversal", "stages_ms_per_step")}
+            if name in ALSO_STRATA:
+                full = scenes_mod.CONFIGS[name]
+                others[name]["slice"] = {"spp_timed": ALSO_STRATA[name][0] * ALSO_STRATA[name][1], "spp_full": full[4] * full[5],
+                                         "extrapolation": "linear in spp: samples are independent passes, Msamples/s carries over; a full frame takes "
+                                                          f"{full[4] * full[5] // (ALSO_STRATA[name][0] * ALSO_STRATA[name][1])} x ms_per_step"}
 
     if rank == 0:
         distinct = {d.get("uuid") or d.get("pci_bus_id") or d["ordinal"] for d in idents}  # one node: ranks on one device share its identity
@@ -324,18 +393,26 @@ def main():
             "shared_gpus": len(distinct) < world,
             "devices": idents,
         }
-        for k in ("mrays_per_s", "rays_per_step", "invalid_samples", "frame_mean_radiance", "gather_ms", "roofline", "traversal", "stages_ms_per_step", "stages"):
+        for k in ("mrays_per_s", "rays_per_step", "closest_rays_per_step", "shadow_rays_per_step", "shade_events_per_step", "mean_path_length",
+                  "rays_per_sample", "paths_at_bounce", "shadow_rays_at_bounce", "invalid_samples", "frame_mean_radiance", "parity_window", "gather_ms",
+                  "roofline_inconsistent", "roofline", "traversal", "stages_ms_per_step", "stages"):
             line[k] = result[k]
         if others:
             line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             sample = tuple(args.cpu_sample) if args.cpu_sample else CPU_SAMPLES[args.config]
             line["cpu_baseline"] = cpu_baseline(args.config, result["config"]["depth"], args.seed, sample, args.integrator)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+        windows = [("main", result["parity_window"])] + [(n, o["parity_window"]) for n, o in others.items()]
+        failed = [n for n, w in windows if w is not None and not (w["bit_exact"] and w["timed_frame_equals_instrumented_frame"])]
+    else:
+        failed = []
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if failed:
+        sys.exit(f"bench.py: the timed frame differs from the oracle in the parity window of: {', '.join(failed)}")
 
 
 if __name__ == "__main__":

@@ -20,8 +20,15 @@
  * seeds (tests/test_gpu_fuzz.py).  The assert sites themselves are counted by the oracle only
  * (`oracle_stats.panics`, test infrastructure): the parity tests assert that count to be zero on the
  * BASELINE scenes.
- * Threading: one `pbrs_ctx` per GPU; different contexts may be driven concurrently from different
- * host threads/processes; a single context is not re-entrant.
+ * Threading: one `pbrs_ctx` per GPU (several on one GPU work too, e.g. one per scene); different contexts may be
+ * driven concurrently from different host threads/processes (tests/test_gpu_contexts.py: two threads, two contexts,
+ * disjoint bands of one frame); a single context is not re-entrant.  Nothing process-wide depends on the scene a
+ * context holds (the kernels' dynamic-LDS limit is raised once per device, to the cap, in `pbrs_create`).
+ * Stream ordering: a context runs on its own NON-BLOCKING stream.  Work the caller queues on the legacy default stream
+ * (or on any other stream) is NOT ordered against a render: the output of `pbrs_render_tile_device` is valid only after
+ * `pbrs_collect_stats`, after the caller has synchronised the context's stream, or — with `pbrs_set_stream` — in the
+ * caller's own stream's order.  `pbrs_render_tile` (host output) synchronises before it returns.
+ * Environment: the library reads no environment variable (developer builds with -DPBRS_DEV_OVERRIDES aside).
  *
  * The flattened scene (`pbrs_scene_desc`) is produced by the host side of the boundary — in the
  * reference's own language that is scene/ + tlas/ + shape/ (Rust); here pbrs_amd/csrc/host
@@ -261,7 +268,14 @@ typedef struct pbrs_stats {
     /* HIP-event time per stage, summed over launches, in ms, on the context's stream */
     float ms_raygen, ms_extend, ms_shade, ms_shadow, ms_accumulate, ms_total;
     uint32_t launches_extend, launches_shadow, launches_shade, passes;
+    /* Queue sizes per bounce, summed over the passes of the render (filled with the work counters): paths_at_bounce[b] = rays
+     * `scene.tlas.intersect` sees at `for bounces in 0..depth` iteration b (src/pathintegrator.rs:14-16), i.e. k_extend's queue;
+     * shadow_rays_at_bounce[b] = `scene.tlas.occludes` calls of that iteration's light estimate (k_shadow's queue).
+     * Bounces beyond PBRS_STATS_MAX_BOUNCES - 1 are added to the last entry. */
+    uint64_t paths_at_bounce[16];
+    uint64_t shadow_rays_at_bounce[16];
 } pbrs_stats;
+#define PBRS_STATS_MAX_BOUNCES 16
 
 typedef struct pbrs_ctx pbrs_ctx;
 
@@ -269,7 +283,8 @@ typedef struct pbrs_ctx pbrs_ctx;
 int pbrs_create(int device_ordinal, pbrs_ctx** out);
 void pbrs_destroy(pbrs_ctx*);
 const char* pbrs_last_error(const pbrs_ctx*);
-/* Run the pipeline on an existing HIP stream (e.g. torch's current stream); NULL = the context's own. */
+/* Run the pipeline on an existing HIP stream (e.g. torch's current stream); NULL = the context's own, which is
+ * created hipStreamNonBlocking: see "Stream ordering" above. */
 int pbrs_set_stream(pbrs_ctx*, void* hip_stream);
 
 /* Copies the flattened scene into HBM.  Stands for building `Scene` (scene/src/lib.rs:36-63). */

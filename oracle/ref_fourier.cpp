@@ -76,6 +76,10 @@ size_t find_interval(size_t size, const std::function<bool(size_t)>& predicate) 
 bool catmull_rom_weights(const std::vector<float>& nodes, float x, long* offset, float w[4]) {  // :203-247
     REF_ASSERT(nodes.size() >= 3);
     if (x < nodes[0] || x > nodes.back()) return false;
+    if (x != x) {  // a NaN passes the test above and trips `assert!(x.inside((x0, x1)))` (:214): a panic site, answered with None
+        ref_panic();
+        return false;
+    }
     size_t i0 = find_interval(nodes.size(), [&](size_t i) { return nodes[i] <= x; });
     size_t i1 = i0 + 1;
     long il = (long)i0 - 1;
@@ -83,6 +87,10 @@ bool catmull_rom_weights(const std::vector<float>& nodes, float x, long* offset,
     float x0 = nodes[i0], x1 = nodes[i1];
     REF_ASSERT(x0 <= x && x <= x1);
     float t = (x - x0) / (x1 - x0);
+    if (!pn_isfinite(t)) {  // x1 == x0 (a repeated node): NaN weights upstream, then an index of -1; the scene builders refuse such tables
+        ref_panic();
+        return false;
+    }
     float t2 = t * t, t3 = t * t * t;
     w[0] = 0.0f;
     w[1] = 2.0f * t3 - 3.0f * t2 + 1.0f;
@@ -124,7 +132,8 @@ bool sample_catmull_rom_2d(const std::vector<float>& nodes_v, const std::vector<
     const size_t nh = nodes_h.size();
     auto interpolate = [&](const std::vector<float>& array2d, size_t col) {
         float sum = 0.0f;
-        for (long i = 0; i < 4; ++i) sum += weights[i] == 0.0f ? 0.0f : array2d[(size_t)(offset + i) * nh + col] * weights[i];
+        for (long i = 0; i < 4; ++i)
+            sum += (weights[i] == 0.0f || (size_t)(offset + i) >= nodes_v.size()) ? 0.0f : array2d[(size_t)(offset + i) * nh + col] * weights[i];
         return sum;
     };
     float maximum = interpolate(cdf, nh - 1);
@@ -225,7 +234,8 @@ static size_t gather_ak(const FourierTable& T, long offset_i, const float* wi4, 
     for (long b = 0; b < 4; ++b)
         for (long a = 0; a < 4; ++a) {
             float weight = wi4[a] * wo4[b];
-            if (weight != 0.0f) {
+            // a knot outside the table (edge intervals) has weight exactly 0; the index test does not rely on it
+            if (weight != 0.0f && (size_t)(offset_i + a) < T.mu.size() && (size_t)(offset_o + b) < T.mu.size()) {
                 size_t m;
                 const float* ap = T.get_ak((size_t)(offset_i + a), (size_t)(offset_o + b), &m);
                 m_max = m > m_max ? m : m_max;
@@ -315,7 +325,7 @@ Prob fourier_prob(const FourierTable& T, Omega wo, Omega wi) {  // :442-485
     for (long i = 0; i < 4; ++i)  // here the mu_i neighbours are the outer loop (:458)
         for (long o = 0; o < 4; ++o) {
             float weight = weights_i[i] * weights_o[o];
-            if (weight == 0.0f) continue;
+            if (weight == 0.0f || (size_t)(offset_i + i) >= T.mu.size() || (size_t)(offset_o + o) >= T.mu.size()) continue;
             size_t order;
             const float* coeffs = T.get_ak((size_t)(offset_i + i), (size_t)(offset_o + o), &order);
             order_max = order > order_max ? order : order_max;
@@ -323,7 +333,7 @@ Prob fourier_prob(const FourierTable& T, Omega wo, Omega wi) {  // :442-485
         }
     float rho = 0.0f;
     for (long o = 0; o < 4; ++o)
-        rho += weights_o[o] == 0.0f ? 0.0f : weights_o[o] * T.cdf[(size_t)(offset_o + o) * T.mu.size() + T.mu.size() - 1] * 2.0f * (float)PI64;
+        rho += (weights_o[o] == 0.0f || (size_t)(offset_o + o) >= T.mu.size()) ? 0.0f : weights_o[o] * T.cdf[(size_t)(offset_o + o) * T.mu.size() + T.mu.size() - 1] * 2.0f * (float)PI64;
     float y = pn_max(fourier_sum(ak.data(), order_max, cos_phi), 0.0f);
     return Prob::Density(rho == 0.0f ? 0.0f : y / rho);
 }

@@ -57,10 +57,11 @@ class Stats(C.Structure):
         "triangles", "tri_shading", "spheres", "quads", "cuboids", "disks", "shadow_tlas_nodes", "shadow_blas_nodes",
         "shadow_instances", "shadow_triangles", "shadow_prims", "invalid_samples")] +
                 [(n, C.c_float) for n in ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow", "ms_accumulate", "ms_total")] +
-                [(n, C.c_uint32) for n in ("launches_extend", "launches_shadow", "launches_shade", "passes")])
+                [(n, C.c_uint32) for n in ("launches_extend", "launches_shadow", "launches_shade", "passes")] +
+                [("paths_at_bounce", C.c_uint64 * 16), ("shadow_rays_at_bounce", C.c_uint64 * 16)])
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n.endswith("_at_bounce") else getattr(self, n)) for n, _ in self._fields_}
 
 
 class RenderParams(C.Structure):
@@ -286,7 +287,9 @@ class Context:
 
     def render_device(self, rgb_device_ptr, strata_x, strata_y, depth, seed, tile=None, samples_per_pass=0, counters=False,
                       timing=False, bands=None, integrator="path"):
-        """Asynchronous: the result lands in caller-owned device memory on the context's stream."""
+        """Asynchronous: the result lands in caller-owned device memory on the context's own NON-BLOCKING stream.  It is valid
+        after `collect_stats()` (which waits for that stream), not merely after work queued later on torch's or the default
+        stream: those are not ordered against it (include/pbrs_gpu.h, "Stream ordering")."""
         p = self._params(strata_x, strata_y, depth, seed, tile, samples_per_pass, counters, timing, bands, integrator)
         self._check(self._L.pbrs_render_tile_device(self._h, C.addressof(self.scene.camera), C.addressof(p), C.c_void_p(rgb_device_ptr), None),
                     "pbrs_render_tile_device")

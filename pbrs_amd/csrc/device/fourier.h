@@ -38,12 +38,16 @@ PD uint32_t find_interval_le(const float* nodes, uint32_t size, float x) {
 }
 // math/src/spline.rs:203-247.  false = None (x outside the nodes).  offset = index of the first of the four knots (-1 .. n - 3)
 PD bool catmull_rom_weights(const float* nodes, uint32_t n, float x, int& offset, float& w0o, float& w1o, float& w2o, float& w3o) {
-    if (x < nodes[0] || x > nodes[n - 1u]) return false;
+    // written so that a NaN x leaves too: upstream a NaN passes `x < nodes[0] || x > nodes[n - 1]` and panics at
+    // `assert!(x.inside((x0, x1)))`; here, as at every panic site of the lobe, the answer is None (black, density 0).  A NaN
+    // direction is reachable: hat() of a zero vector towards a light sample on the surface.
+    if (!(nodes[0] <= x && x <= nodes[n - 1u])) return false;
     const uint32_t i0 = find_interval_le(nodes, n, x), i1 = i0 + 1u;
     const int il = (int)i0 - 1;
     const uint32_t ir = i1 + 1u;
     const float x0 = nodes[i0], x1 = nodes[i1];
     const float t = (x - x0) / (x1 - x0);
+    if (!pn_isfinite(t)) return false;  // x1 == x0: pbrs_upload_scene refuses such tables; kept so that no weight can be NaN
     const float t2 = t * t, t3 = t * t * t;
     float w_0 = 0.0f, w_1 = 2.0f * t3 - 3.0f * t2 + 1.0f, w_2 = -2.0f * t3 + 3.0f * t2, w_3 = 0.0f;
     if (il >= 0) {
@@ -80,6 +84,9 @@ struct FourierNbrs {
     int offset_i, offset_o;
     float wi[4], wo[4];
     PD float weight(int a_, int b_) const { return wi[a_] * wo[b_]; }
+    // a neighbour outside the table (knot -1 or n_mu at an edge interval) has weight exactly 0 whenever the weights are
+    // finite; the index test makes that independent of the arithmetic: no lane reads outside the table's arrays
+    PD bool inside(int a_, int b_) const { return (uint32_t)(offset_o + b_) < n_mu && (uint32_t)(offset_i + a_) < n_mu; }
     // largest series length among the neighbours with a non-zero weight (the reference's running `m_max`)
     PD uint32_t order() const {
         uint32_t m_max = 0;
@@ -87,7 +94,7 @@ struct FourierNbrs {
         for (int b_ = 0; b_ < 4; ++b_)
 #pragma unroll
             for (int a_ = 0; a_ < 4; ++a_)
-                if (weight(a_, b_) != 0.0f) {
+                if (weight(a_, b_) != 0.0f && inside(a_, b_)) {
                     const uint32_t m = m_lookup[(uint32_t)(offset_o + b_) * n_mu + (uint32_t)(offset_i + a_)];
                     m_max = m > m_max ? m : m_max;
                 }
@@ -101,7 +108,7 @@ struct FourierNbrs {
 #pragma unroll
             for (int a_ = 0; a_ < 4; ++a_) {
                 const float w = weight(a_, b_);
-                if (w != 0.0f) {
+                if (w != 0.0f && inside(a_, b_)) {
                     const uint32_t index = (uint32_t)(offset_o + b_) * n_mu + (uint32_t)(offset_i + a_);
                     const uint32_t m = m_lookup[index];
                     if (k < m) acc += w * a[a_offset[index] + channel * m + k];
@@ -117,7 +124,7 @@ struct FourierNbrs {
 #pragma unroll
             for (int b_ = 0; b_ < 4; ++b_) {
                 const float w = weight(a_, b_);
-                if (w == 0.0f) continue;
+                if (w == 0.0f || !inside(a_, b_)) continue;
                 const uint32_t index = (uint32_t)(offset_o + b_) * n_mu + (uint32_t)(offset_i + a_);
                 const uint32_t m = m_lookup[index];
                 if (k < m) acc += a[a_offset[index] + k] * w;
@@ -178,7 +185,7 @@ PD ProbD fourier_prob(const FourierView& V, const pbrs_fourier_table& T, f3 wo, 
     float rho = 0.0f;
 #pragma unroll
     for (int o = 0; o < 4; ++o)
-        rho += N.wo[o] == 0.0f ? 0.0f : N.wo[o] * cdf[(uint32_t)(N.offset_o + o) * T.n_mu + T.n_mu - 1u] * 2.0f * PN_PI;
+        rho += (N.wo[o] == 0.0f || (uint32_t)(N.offset_o + o) >= T.n_mu) ? 0.0f : N.wo[o] * cdf[(uint32_t)(N.offset_o + o) * T.n_mu + T.n_mu - 1u] * 2.0f * PN_PI;
     const float y = pn_max(fourier_sum([&](uint32_t k) { return N.coef_io(k); }, order_max, cos_phi), 0.0f);
     return density(rho == 0.0f ? 0.0f : y / rho);
 }
@@ -230,7 +237,7 @@ PD bool sample_catmull_rom_2d(const float* nodes, uint32_t n, const float* value
     auto interpolate = [&](const float* array2d, uint32_t col) {
         float sum = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sum += w[i] == 0.0f ? 0.0f : array2d[(uint32_t)(offset + i) * n + col] * w[i];
+        for (int i = 0; i < 4; ++i) sum += (w[i] == 0.0f || (uint32_t)(offset + i) >= n) ? 0.0f : array2d[(uint32_t)(offset + i) * n + col] * w[i];
         return sum;
     };
     const float maximum = interpolate(cdf, n - 1u);

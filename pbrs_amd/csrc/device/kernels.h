@@ -1107,6 +1107,16 @@ __global__ void __launch_bounds__(256) k_finalize(const float* sum, float* rgb, 
     rgb[3 * p + 2] = sum[2 * n_pixels + p] * inv_spp;
 }
 
+// Instrumented renders only: the queue sizes of one pass, bounce by bounce, added to the render's totals (pbrs_stats).
+// act[b] = paths entering bounce b >= 1 (bounce 0: the pass itself), ns[b] = (shadow rays << 32 | two-ray estimates) of bounce b.
+__global__ void k_sum_bounce_counts(const uint32_t* act, const unsigned long long* ns, uint32_t n_pass, uint32_t n_bounces, unsigned long long* acc) {
+    const uint32_t b = threadIdx.x;
+    if (b >= n_bounces) return;
+    const uint32_t at = b < PBRS_STATS_MAX_BOUNCES ? b : PBRS_STATS_MAX_BOUNCES - 1u;
+    atomicAdd(acc + at, (unsigned long long)(b == 0 ? n_pass : act[b]));
+    atomicAdd(acc + PBRS_STATS_MAX_BOUNCES + at, ns[b] >> 32);
+}
+
 // ---- parity-harness kernels --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, const float4* origins, const float4* dirs, const float* tmax,
                                                        pbrs_hit_record* hits, uint8_t* occluded) {

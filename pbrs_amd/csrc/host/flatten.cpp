@@ -658,9 +658,11 @@ int pbrs_host_scene_build(const pbrs_scene_spec* spec, pbrs_host_scene** out) {
             g_error = "Fourier table: bad sizes or missing arrays";
             return PBRS_E_INVALID;
         }
-        for (size_t i = 0; i + 1 < n; ++i)
-            if (!(fs.mu[i] <= fs.mu[i + 1])) {
-                g_error = "Fourier table: mu is not ascending";  // :198-200
+        // :198-200 asserts mu[i] <= mu[i + 1]; a repeated or non-finite node makes catmull_rom_weights divide 0 by 0 there
+        // (NaN weights, then a knot index of -1 upstream): such a table is refused here
+        for (size_t i = 0; i < n; ++i)
+            if (!pn_isfinite(fs.mu[i]) || (i + 1 < n && !(fs.mu[i] < fs.mu[i + 1]))) {
+                g_error = "Fourier table: mu is not finite and strictly ascending";
                 return PBRS_E_INVALID;
             }
         int32_t m_max = 0;

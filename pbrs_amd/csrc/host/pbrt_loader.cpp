@@ -725,10 +725,19 @@ static std::unique_ptr<RawBsdf> load_bsdf(const std::string& path) {
     std::memcpy(alpha, h + 48, 8);
     if (!std::isfinite(eta) || !std::isfinite(alpha[0]) || !std::isfinite(alpha[1])) fail("BSDF header holds a non-finite eta or alpha: " + path);
     if (n_mu < 3 || n_mu > 4096 || n_coeffs < 0 || (n_channels != 1 && n_channels != 3)) fail("BSDF header sizes are out of range: " + path);
+    const size_t nn = (size_t)n_mu * (size_t)n_mu;
+    {
+        // the header is not trusted with memory: the file must be as long as it claims before anything is sized from it
+        // (n_coeffs alone may ask for 8 GiB; a 64-byte file must not be able to exhaust the host)
+        const uint64_t need = 64ull + 4ull * (uint64_t)n_mu + 12ull * (uint64_t)nn + 4ull * (uint64_t)n_coeffs;
+        f.seekg(0, std::ios::end);
+        const std::streamoff size = f.tellg();
+        if (size < 0 || (uint64_t)size < need) fail("BSDF file is truncated: its header announces " + std::to_string(need) + " bytes: " + path);
+        f.seekg(64, std::ios::beg);
+    }
     auto b = std::make_unique<RawBsdf>();
     b->n_channels = (uint32_t)n_channels;
     b->eta = eta;
-    const size_t nn = (size_t)n_mu * (size_t)n_mu;
     b->mu.resize((size_t)n_mu);
     b->cdf.resize(nn);
     b->offset_and_length.resize(2 * nn);

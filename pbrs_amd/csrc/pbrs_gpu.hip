@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,17 @@ struct StageEvent {
     int stage;  // 0 raygen, 1 extend, 2 shade, 3 shadow, 4 accumulate
     hipEvent_t a, b;
 };
+
+// Developer overrides (A/B timing of kernel selection: tools/ab_env.sh) exist only in builds made with -DPBRS_DEV_OVERRIDES.
+// The shipped library never reads the environment: a bench line must not depend on the box it ran on.
+inline const char* dev_env(const char* name) {
+#ifdef PBRS_DEV_OVERRIDES
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 }  // namespace
 
@@ -57,6 +69,7 @@ struct pbrs_ctx {
     float* rgb_dev = nullptr;     // 3 * cap_pixels, row-major (for the host-output variant)
     GlobalCounters* gcnt = nullptr;  // [0] extend, [1] shadow
     unsigned long long* nonfinite = nullptr;  // samples of the current render whose radiance is not finite
+    unsigned long long* bounce_acc = nullptr; // 2 x PBRS_STATS_MAX_BOUNCES: queue sizes per bounce of the current instrumented render
 
     // timing
     std::vector<StageEvent> events;
@@ -182,9 +195,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
 
 size_t lds_bytes(const pbrs_ctx* c) {
     size_t b = (size_t)(c->stack_depth) * kBlock * sizeof(uint32_t);
-#ifdef PBRS_PROBE_LDS_PAD  // developer probe: lowers the occupancy of the traversal kernels
-    if (const char* e = getenv("PBRS_LDS_MIN")) b = b < (size_t)atol(e) ? (size_t)atol(e) : b;
-#endif
+    if (const char* e = dev_env("PBRS_LDS_MIN")) b = b < (size_t)atol(e) ? (size_t)atol(e) : b;  // lowers the occupancy of the traversal kernels
     return b;
 }
 
@@ -249,13 +260,13 @@ RenderConst make_const(const pbrs_camera* cam, const pbrs_render_params* p) {
     // slot order of a pass (kernels.h, sample_of_slot): chunks of 4 K pixels, a multiple of the block and of the wave (C4:
     // 1156 Msamples/s with the sample index outermost, 1208-1211 with chunks of 256 ... 16 K pixels, 1202 with 64 K)
     rc.chunk_pixels = 4096u;
-    if (const char* e = getenv("PBRS_RAYGEN_CHUNK")) {  // developer override (A/B timing): 0 = sample index outermost, as in round 1
+    if (const char* e = dev_env("PBRS_RAYGEN_CHUNK")) {  // developer override (A/B timing): 0 = sample index outermost, as in round 1
         const long v = std::atol(e);
         rc.chunk_pixels = v > 0 ? (uint32_t)v : 0xffffffffu;
     }
     if (rc.chunk_pixels > rc.n_pixels) rc.chunk_pixels = rc.n_pixels;  // one chunk: slot = k * P + pixel
     rc.tiles8_per_row = (p->w % 8u == 0u && p->h % 8u == 0u) ? p->w / 8u : 0u;
-    if (const char* e = getenv("PBRS_RAYGEN_TILES8")) {  // developer override (A/B timing)
+    if (const char* e = dev_env("PBRS_RAYGEN_TILES8")) {  // developer override (A/B timing)
         if (std::atoi(e) == 0) rc.tiles8_per_row = 0u;
     }
     return rc;
@@ -439,6 +450,8 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         hipLaunchKernelGGL(k_nee_resolve, dim3(sgrid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
         tm.end();
     }
+    if (stats)  // queue sizes of this pass, bounce by bounce (the counters are cleared at the start of every pass)
+        hipLaunchKernelGGL(k_sum_bounce_counts, dim3(1), dim3(64), 0, c->stream, act, ns, N, n_bounces, c->bounce_acc);
     if (tm.begin(4)) return fail(c, PBRS_E_DEVICE, "event record failed");
     hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, c->sum, P, kc, rc.chunk_pixels, rc.w, rc.tiles8_per_row, c->nonfinite);
     tm.end();
@@ -464,6 +477,7 @@ int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params*
     c->pending_times = p->time_stages != 0;
     c->pending.samples = (uint64_t)P * spp;
     if (stats) HIPCHK(c, hipMemsetAsync(c->gcnt, 0, 2 * sizeof(GlobalCounters), c->stream));
+    if (stats) HIPCHK(c, hipMemsetAsync(c->bounce_acc, 0, 2 * PBRS_STATS_MAX_BOUNCES * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->nonfinite, 0, sizeof(unsigned long long), c->stream));
     if (c->pending_times) HIPCHK(c, hipEventRecord(c->total_ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->sum, 0, 3 * (size_t)P * sizeof(float), c->stream));
@@ -503,6 +517,12 @@ int collect(pbrs_ctx* c, pbrs_stats* out) {
         s.shadow_tlas_nodes = g[1].tlas_nodes; s.shadow_blas_nodes = g[1].blas_nodes; s.shadow_instances = g[1].instances;
         s.shadow_triangles = g[1].triangles;
         s.shadow_prims = g[1].spheres + g[1].quads + g[1].cuboids + g[1].disks;
+        unsigned long long per_bounce[2 * PBRS_STATS_MAX_BOUNCES];
+        HIPCHK(c, hipMemcpy(per_bounce, c->bounce_acc, sizeof per_bounce, hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b < PBRS_STATS_MAX_BOUNCES; ++b) {
+            s.paths_at_bounce[b] = per_bounce[b];
+            s.shadow_rays_at_bounce[b] = per_bounce[PBRS_STATS_MAX_BOUNCES + b];
+        }
     }
     if (c->pending_times) {
         float* acc[5] = {&s.ms_raygen, &s.ms_extend, &s.ms_shade, &s.ms_shadow, &s.ms_accumulate};
@@ -514,6 +534,32 @@ int collect(pbrs_ctx* c, pbrs_stats* out) {
         HIPCHK(c, hipEventElapsedTime(&s.ms_total, c->total_ev[0], c->total_ev[1]));
     }
     if (out) *out = s;
+    return PBRS_OK;
+}
+
+// The traversal kernels take their per-lane stacks from dynamic LDS.  The limit a kernel may ask for is per-function state
+// of the PROCESS (hipFuncSetAttribute), not of a context: it is raised once per device, to the most any scene may need
+// (pbrs_upload_scene refuses stacks above kLdsBytesPerCU / 2), so that contexts holding scenes with different stack depths
+// can render side by side — rewriting it per upload let the last upload decide for every context of the process.
+std::mutex g_kernel_cfg_mutex;
+bool g_kernel_cfg_done[64] = {};
+int configure_kernels(pbrs_ctx* c) {
+    std::lock_guard<std::mutex> lock(g_kernel_cfg_mutex);
+    if (c->device < 64 && g_kernel_cfg_done[c->device]) return PBRS_OK;
+    const int cap = (int)(kLdsBytesPerCU / 2);
+#define PBRS_K(expr) reinterpret_cast<const void*>(&expr)
+    const void* traversal_kernels[] = {
+        PBRS_K((k_extend<false, 0u>)),  PBRS_K((k_extend<false, 1u>)),  PBRS_K((k_extend<false, 2u>)),  PBRS_K((k_extend<false, 3u>)),
+        PBRS_K((k_extend<false, 4u>)),  PBRS_K((k_extend<false, 5u>)),  PBRS_K((k_extend<false, 6u>)),  PBRS_K((k_extend<false, 7u>)),
+        PBRS_K((k_extend<false, 8u>)),  PBRS_K((k_extend<false, 9u>)),  PBRS_K((k_extend<false, 10u>)), PBRS_K((k_extend<false, 11u>)),
+        PBRS_K((k_extend<false, 12u>)), PBRS_K((k_extend<false, 13u>)), PBRS_K((k_extend<false, 14u>)), PBRS_K((k_extend<false, 15u>)),
+        PBRS_K((k_extend<true, PBRS_FEAT_ALL>)),
+        PBRS_K((k_shadow<false, 0u>)), PBRS_K((k_shadow<false, 1u>)), PBRS_K((k_shadow<false, 4u>)), PBRS_K((k_shadow<false, 5u>)),
+        PBRS_K((k_shadow<false, 8u>)), PBRS_K((k_shadow<false, 9u>)), PBRS_K((k_shadow<false, 12u>)), PBRS_K((k_shadow<false, 13u>)),
+        PBRS_K((k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>)), PBRS_K(k_intersect_rays)};
+#undef PBRS_K
+    for (const void* k : traversal_kernels) HIPCHK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    if (c->device < 64) g_kernel_cfg_done[c->device] = true;
     return PBRS_OK;
 }
 
@@ -543,8 +589,8 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     // waits for the frames queued here nor holds them up
     bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
     c->stream = c->own_stream;
-    if (const char* e = getenv("PBRS_SORT_CLASSES")) c->sort_classes = std::atoi(e) != 0;
-    if (const char* e = getenv("PBRS_SPLIT_LAMBERT")) c->split_lambert = std::atoi(e) != 0;
+    if (const char* e = dev_env("PBRS_SORT_CLASSES")) c->sort_classes = std::atoi(e) != 0;
+    if (const char* e = dev_env("PBRS_SPLIT_LAMBERT")) c->split_lambert = std::atoi(e) != 0;
     for (int k = 0; ok && k < 2; ++k) {
         hipEvent_t ev = nullptr;
         ok = hipEventCreate(&ev) == hipSuccess;
@@ -553,7 +599,9 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&c->nonfinite), sizeof(unsigned long long)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&c->bounce_acc), 2 * PBRS_STATS_MAX_BOUNCES * sizeof(unsigned long long)) == hipSuccess &&
          hipMemset(c->nonfinite, 0, sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && configure_kernels(c) == PBRS_OK;
     if (!ok) {
         pbrs_destroy(c);
         return PBRS_E_DEVICE;
@@ -571,6 +619,7 @@ void pbrs_destroy(pbrs_ctx* c) {
     if (c->counters) (void)hipFree(c->counters);
     if (c->gcnt) (void)hipFree(c->gcnt);
     if (c->nonfinite) (void)hipFree(c->nonfinite);
+    if (c->bounce_acc) (void)hipFree(c->bounce_acc);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -642,8 +691,9 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             fourier = true;
         }
     }
-    // Fourier tables (geometry/src/fourier.rs:99-151): every array inside the pools, every series inside the coefficients,
-    // so that no lane can index outside them whatever the directions
+    // Fourier tables (geometry/src/fourier.rs:99-151): every array inside the pools, every series inside the coefficients;
+    // with finite, strictly ascending nodes the interpolation weights are finite for every direction the lobe accepts (a NaN
+    // direction is refused there), and the lobe skips neighbours outside the table: no lane indexes outside the pools
     for (uint32_t i = 0; i < d->n_fourier_tables; ++i) {
         const pbrs_fourier_table& t = d->fourier_tables[i];
         const uint64_t n = t.n_mu, nn = n * n, nf = d->n_tex_floats, nw = d->n_tex_words;
@@ -651,6 +701,10 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         if (t.mu + n > nf || t.cdf + nn > nf || t.a0 + nn > nf || (uint64_t)t.a + t.n_coeffs > nf || (uint64_t)t.recip + t.m_max > nf ||
             t.a_offset + nn > nw || t.m_lookup + nn > nw)
             return fail(c, PBRS_E_INVALID, "Fourier table: arrays out of range");
+        for (uint64_t k = 0; k < n; ++k) {  // finite, strictly ascending nodes: no interval of zero width, no NaN weight (device/fourier.h)
+            const float m0 = d->tex_floats[t.mu + k];
+            if (!pn_isfinite(m0) || (k + 1 < n && !(m0 < d->tex_floats[t.mu + k + 1]))) return fail(c, PBRS_E_INVALID, "Fourier table: mu is not finite and strictly ascending");
+        }
         for (uint64_t k = 0; k < nn; ++k) {
             const uint64_t off = d->tex_words[t.a_offset + k], len = d->tex_words[t.m_lookup + k];
             if (len > t.m_max || off + len * t.n_channels > t.n_coeffs) return fail(c, PBRS_E_INVALID, "Fourier table: series out of range");
@@ -697,6 +751,9 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     const uint32_t tlas_levels = th[0];
     max_blas_height = 0;
     for (uint32_t i = 0; i < d->n_meshes; ++i) max_blas_height = std::max(max_blas_height, bh[d->meshes[i].root]);
+    // a walk enters a BLAS through the instance's own blas_root (range-checked above), which need not be a listed mesh root
+    for (uint32_t i = 0; i < d->n_instances; ++i)
+        if (d->instances[i].shape_kind == PBRS_SHAPE_MESH) max_blas_height = std::max(max_blas_height, bh[d->instances[i].blas_root]);
     uint32_t depth = std::max(tlas_levels, tlas_levels - 1u + max_blas_height);
     if ((size_t)depth * kBlock * sizeof(uint32_t) > kLdsBytesPerCU / 2) return fail(c, PBRS_E_LIMIT, "traversal stack exceeds the LDS budget");
     (void)hipStreamSynchronize(c->stream);
@@ -794,10 +851,10 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         S.fast_slab = ok ? 1u : 0u;
     }
     S.refill_below = max_blas_height >= PBRS_LONG_WALK_HEIGHT ? PBRS_REFILL_BELOW_LONG : PBRS_REFILL_BELOW_SHORT;
-    if (const char* e = getenv("PBRS_REFILL_BELOW")) S.refill_below = (uint32_t)std::atoi(e);  // developer override (A/B timing)
+    if (const char* e = dev_env("PBRS_REFILL_BELOW")) S.refill_below = (uint32_t)std::atoi(e);  // developer override (A/B timing)
     // long walks: the levels a ray actually walks — the deepest BLAS, plus the TLAS where it is not scanned
     c->long_walks = (S.n_flat ? 0u : tlas_levels) + max_blas_height >= PBRS_LONG_WALK_HEIGHT;
-    if (const char* e = getenv("PBRS_LONG_WALKS")) c->long_walks = std::atoi(e) != 0;  // developer override (A/B timing)
+    if (const char* e = dev_env("PBRS_LONG_WALKS")) c->long_walks = std::atoi(e) != 0;  // developer override (A/B timing)
     // the leaf copies serve k_shadow up to PBRS_FLAT_TLAS_MAX_ANYHIT instances, k_extend up to PBRS_FLAT_TLAS_MAX
     c->shadow_flat = S.n_flat != 0u;
     const uint32_t flat_feature = (S.n_flat != 0u && d->n_instances <= PBRS_FLAT_TLAS_MAX) ? PBRS_FEAT_FLAT_TLAS : 0u;
@@ -834,7 +891,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         // the light shape alone does not pay: without the Lambert cut the kernel grows to 135-141 VGPRs, three waves per SIMD
         // (C2 shade 110.5 -> 117.0 ms, C4 150.6 -> 169.3)
         uint32_t spec = lambert ? (PBRS_SHADE_LAMBERT | light_spec) : 0u;
-        if (const char* e = getenv("PBRS_SHADE_SPEC")) spec &= (uint32_t)std::atoi(e);  // developer override (A/B timing): a mask
+        if (const char* e = dev_env("PBRS_SHADE_SPEC")) spec &= (uint32_t)std::atoi(e);  // developer override (A/B timing): a mask
         c->shade_spec = spec;
     }
     c->S = S;
@@ -843,20 +900,6 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     c->has_vis_records = vis_records;
     c->stack_depth = depth;
     c->has_scene = true;
-    size_t lds = lds_bytes(c);
-#define PBRS_K(expr) reinterpret_cast<const void*>(&expr)
-    const void* traversal_kernels[] = {
-        PBRS_K((k_extend<false, 0u>)),  PBRS_K((k_extend<false, 1u>)),  PBRS_K((k_extend<false, 2u>)),  PBRS_K((k_extend<false, 3u>)),
-        PBRS_K((k_extend<false, 4u>)),  PBRS_K((k_extend<false, 5u>)),  PBRS_K((k_extend<false, 6u>)),  PBRS_K((k_extend<false, 7u>)),
-        PBRS_K((k_extend<false, 8u>)),  PBRS_K((k_extend<false, 9u>)),  PBRS_K((k_extend<false, 10u>)), PBRS_K((k_extend<false, 11u>)),
-        PBRS_K((k_extend<false, 12u>)), PBRS_K((k_extend<false, 13u>)), PBRS_K((k_extend<false, 14u>)), PBRS_K((k_extend<false, 15u>)),
-        PBRS_K((k_extend<true, PBRS_FEAT_ALL>)),
-        PBRS_K((k_shadow<false, 0u>)), PBRS_K((k_shadow<false, 1u>)), PBRS_K((k_shadow<false, 4u>)), PBRS_K((k_shadow<false, 5u>)),
-        PBRS_K((k_shadow<false, 8u>)), PBRS_K((k_shadow<false, 9u>)), PBRS_K((k_shadow<false, 12u>)), PBRS_K((k_shadow<false, 13u>)),
-        PBRS_K((k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>))};
-#undef PBRS_K
-    for (const void* k : traversal_kernels) HIPCHK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect_rays), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return PBRS_OK;
 }
 

@@ -3,40 +3,57 @@
 Every stage's algorithmic bytes are split in two:
 
 * queue_state bytes — ray / hit / shadow-ray records, path state and queue entries.  They are written by one kernel
-  and read by the next, tens of GB apart: they MUST cross HBM.  Per unit: 52 B per closest-hit ray,
-  68 B per shadow ray, 320 B per shade event, 36 B per accumulated sample.
+  and read by the next, tens of GB apart: they MUST cross HBM.  The per-unit figures are those of the record layout the
+  kernels actually move (device/kernels.h, PathState; PBRS_STATE_BYTES_PER_PATH is the resident footprint of one path):
+    closest-hit ray  48 B   32 B ray read (origin + slot, direction + RNG word: two 16-byte vectors) + 16 B hit record written
+                            (+ 1 B class byte in scenes with several shading classes)
+    shadow ray       44 B   32 B ray read + the lone ray's outcome: 16 B read, 12 B written when unoccluded (an occlusion byte
+                            otherwise); priced at the unoccluded case of the common lone ray
+    shade event     192 B   64 B read (three path vectors + hit) + 32 B radiance read-modify-write + 48 B next path record +
+                            48 B for the one shadow ray most vertices cast (two vectors + its outcome vector)
+    accumulated sample 28 B 16 B radiance vector read + 12 B of the pixel sum, amortised over the pass
+  SURVEY.md §8(d) priced the same events at 52 / 68 / 320 / 36 B for the column layout it sketched (round 1's); the dense
+  16-byte records of round 2 move fewer bytes, and the model follows the records so that `achieved` is not flattered.
 * scene bytes — BVH nodes, instances, triangles, analytic shapes: 32 B per node visit, 64 (+48) B per instance, 48 B per
   triangle test, ...  The scene is read-only and cache-resident (C2 / C3: a few KB, in every L2; C4: 137 MB, in the
   Infinity Cache with its upper levels in L2), so these bytes are a WORK RATE, not HBM traffic: priced at record size
   they exceed the HBM peak on a cache-resident scene (round 1's 1.03).
 
-The HBM roofline of a stage is therefore
+The HBM roofline of a stage is
     achieved = (queue_state bytes + scene bytes that missed the caches) / kernel time
 where the scene misses come from the measured traffic of that kernel (rocprofv3 TCC counters, separate passes,
 profiles/latest_traffic_<config>.json): misses = clamp(traffic - queue_state bytes, 0, scene bytes), and 0 for a scene
-that fits one XCD's L2.  Without a traffic file the misses count as 0 and the line says so.  achieved <= traffic-derived
-bytes <= what HBM can move, so frac <= 1 by construction; bench.py asserts it.
+that fits one XCD's L2.  Without a traffic file the misses count as 0 and the line says so.  The queue/state bytes are a
+MODEL (units x record sizes), not a measurement: `frac_measured` = measured traffic / time / peak is reported beside the
+model fraction wherever a traffic file applies, and a model fraction above 1 is flagged (`roofline_inconsistent`), not
+asserted away.  The traffic counters (FETCH_SIZE / WRITE_SIZE / TCC_EA0_*) count L2 -> fabric requests INCLUDING
+Infinity-Cache hits (guide §HBM): for a scene that fits the 256 MiB Infinity Cache they are an upper bound of true HBM
+traffic, hence the `l2_fabric_*` names.
 
 Counts come from the instrumented kernel variant (pbrs_render_params.collect_counters): traversal is deterministic, so
 they equal the timed work (and the oracle's counts, tests/test_gpu_render.py).  The instrumented k_extend evaluates
 the full feature set; what the lean variants skip (tri_shading fetches of shading-proved meshes) is scene work only.
 """
+import hashlib
+import os
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
 L2_BYTES_PER_XCD = 4 << 20
 N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs (same guide)
 CLOCK_HZ = 2.4e9        # peak engine clock (same guide); the sustained clock is lower, so issue fractions are lower bounds
 CYCLES_PER_WAVE_VALU = 4  # a wave64 vector instruction occupies its 16-lane SIMD for 4 cycles
 
-B_CLOSEST_RAY = 52    # queue read (o 12, d 12, t_max 4, path id 4) + hit write (t, inst, prim, b1, b2 = 20)
-B_SHADOW_RAY = 68     # queue read 32 + pending contribution 12 + radiance r/w 24
+B_CLOSEST_RAY = 48    # two 16-byte ray vectors read + the 16-byte hit record written (PathState::q[.][0..1], ::hit)
+B_SHADOW_RAY = 44     # two 16-byte ray vectors read (::sr[0..1]) + a lone ray's outcome: 16 B read (::sr[2]), 12 B into L
 B_NODE = 32           # bbox 24 + links/range/axis 8
 B_INSTANCE = 64       # inverse 3x4 (48) + kind/ids (16)
 B_INSTANCE_HIT = 48   # forward 3x4 on an accepted hit
 B_TRIANGLE = 48       # three positions (+ padding lanes that carry the id)
 B_TRI_SHADING = 60    # 3 normals 36 + 3 uvs 24
 B_SPHERE, B_CUBOID, B_QUAD, B_DISK = 16, 24, 36, 36
-B_SHADE = 320         # path state r/w 72 + material 64 + light 64 + new ray 32 + 2 shadow items 88
-B_SAMPLE = 36         # accumulate: read L 12 + r/w pixel sum 24
+B_SHADE = 192         # q[.][0..2] + hit read 64, L read-modify-write 32, next path record 48, one shadow ray (sr[0..2]) 48
+B_SAMPLE = 28         # accumulate: L vector read 16 + the pixel sum's 12 (read and written once per pass)
+SURVEY_8D = {"closest_ray": 52, "shadow_ray": 68, "shade_event": 320, "sample": 36}  # the column layout SURVEY.md §8(d) priced
 
 
 def extend_queue_bytes(s):
@@ -90,7 +107,7 @@ def kernel_traffic(traffic_doc, kernel, stage_launches_per_frame=None):
     n = sum(v["launches"] for v in rows)
     if not n:
         return None
-    total = sum(v["hbm_total"] * v["launches"] for v in rows)
+    total = sum(v.get("l2_fabric_total", v.get("hbm_total", 0.0)) * v["launches"] for v in rows)
     frames = traffic_doc.get("geometry", {}).get("frames")
     if stage_launches_per_frame and frames:
         return total / (frames * stage_launches_per_frame)
@@ -144,6 +161,8 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None):
             "cache_work_rate_GBps": ((q + sc) / sec / 1e9) if sec > 0 else 0.0,  # not an HBM figure: may exceed the HBM peak
         }
         out[stage]["frac"] = out[stage]["achieved_GBps"] / HBM_PEAK_GBS
+        # what the counters saw (L2 -> fabric requests, Infinity-Cache hits included), beside the model
+        out[stage]["frac_measured"] = (traffic / sec / 1e9 / HBM_PEAK_GBS) if (traffic is not None and sec > 0) else None
         valu = kernel_valu(traffic_doc, kernel, launches)
         if valu and sec > 0:
             # share of the chip's vector issue slots the kernel fills (instruction counts measured offline, time live): what
@@ -169,3 +188,26 @@ def traversal(report):
             "cache_work_rate_GBps": work / sec / 1e9 if sec > 0 else 0.0,
             "note": "achieved = queue/state bytes + measured scene misses; cache_work_rate prices every node / triangle visit at record size "
                     "(SURVEY.md §8d) and is served by L2 / Infinity Cache, so it is not comparable with the HBM peak"}
+
+
+def bound_of(stage_row):
+    """"valu_issue" when the kernel fills a larger share of the chip's vector issue slots than of the HBM peak, else "hbm"."""
+    v = stage_row.get("valu_issue_frac")
+    return "valu_issue" if (v is not None and v > stage_row["frac"]) else "hbm"
+
+
+def source_hash(root=None):
+    """sha256 over the sources the kernels are built from (pbrs_amd/csrc/**, include/*.h): stamps a traffic file
+    (tools/profile_frame.py -> tools/traffic_from_pmc.py) so that bench.py can tell whether the offline counters it
+    quotes were measured on the kernels it is timing."""
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for base in (os.path.join(root, "pbrs_amd", "csrc"), os.path.join(root, "include")):
+        for d, _, names in os.walk(base):
+            files += [os.path.join(d, n) for n in names if n.endswith((".h", ".hip", ".cpp")) or n == "Makefile"]
+    h = hashlib.sha256()
+    for f in sorted(files):
+        h.update(os.path.relpath(f, root).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

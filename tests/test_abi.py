@@ -76,3 +76,14 @@ def test_product_path_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"(^|\n)\s*(from|import)\s+oracle\b", text), os.path.join(dirpath, f)
                 assert "libpbrs_oracle" not in text and "oracle/" not in text.replace("the CPU oracle in oracle/", ""), os.path.join(dirpath, f)
+
+
+def test_the_shipped_hip_library_does_not_read_the_environment():
+    """Kernel selection must not depend on the box a bench runs on: the developer overrides live behind -DPBRS_DEV_OVERRIDES
+    and the shipped libpbrs_gpu.so does not import getenv at all."""
+    import subprocess
+    from pbrs_amd import api
+    syms = subprocess.run(["nm", "-D", "--undefined-only", api.lib_paths()[1]], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    src = open(os.path.join(ROOT, "pbrs_amd", "csrc", "pbrs_gpu.hip")).read()
+    assert src.count("getenv(") == 1 and "#ifdef PBRS_DEV_OVERRIDES" in src  # the one call sits inside dev_env()

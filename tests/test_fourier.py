@@ -50,13 +50,18 @@ def test_host_flattener_lays_the_table_into_the_pools():
     assert kinds is None or 3 in kinds
 
 
-@pytest.mark.parametrize("breakage,needle", [("descending", "ascending"), ("series", "outside"), ("channels", "sizes"), ("index", "missing table")])
+@pytest.mark.parametrize("breakage,needle", [("descending", "ascending"), ("repeated", "strictly ascending"), ("nan", "finite"), ("series", "outside"),
+                                             ("channels", "sizes"), ("index", "missing table")])
 def test_malformed_tables_are_errors(breakage, needle):
     t = fourier_scenes.table("mono")
     t = fourier.FourierTable(t.mu.copy(), t.cdf.copy(), t.offset_and_length.copy(), t.a.copy(), t.n_channels)
     sb = SceneBuilder()
     if breakage == "descending":
         t.mu[3], t.mu[4] = t.mu[4], t.mu[3]
+    if breakage == "repeated":  # an interval of zero width: catmull_rom_weights would divide 0 by 0 at that node
+        t.mu[4] = t.mu[3]
+    if breakage == "nan":
+        t.mu[2] = np.nan
     if breakage == "series":
         t.offset_and_length[5, 0] = len(t.a)
         t.offset_and_length[5, 1] = 4
@@ -138,4 +143,29 @@ WorldEnd
     with pytest.raises(pbrs_amd.PbrsError) as e:
         pbrs_amd.load_pbrt(str(tmp_path / "short.pbrt"))
     assert "truncated" in str(e.value)
+    # a header that announces 2^31 - 1 coefficients on a file of a few KB must fail on the file size, before anything is sized from it
+    raw = bytearray((tmp_path / "paintlike.bsdf").read_bytes())
+    raw[16:20] = struct.pack("<i", 2**31 - 1)
+    (tmp_path / "huge.bsdf").write_bytes(bytes(raw))
+    (tmp_path / "huge.pbrt").write_text((tmp_path / "s.pbrt").read_text().replace("paintlike.bsdf", "huge.bsdf"))
+    with pytest.raises(pbrs_amd.PbrsError) as e:
+        pbrs_amd.load_pbrt(str(tmp_path / "huge.pbrt"))
+    assert "truncated" in str(e.value)
     assert a.mean() > 0.005
+
+
+def nan_light_scene():
+    """Every vertex lit by a distant light whose direction is NaN (DeltaLight::Distant hands `-casting_dir` to the BSDF as it
+    is, light/src/lib.rs:77-89) or by a sound point light: the Fourier lobe meets NaN directions at every other estimate."""
+    sb = fourier_scenes.scene(("rgb", "mono", "fine"), "point", size=(40, 28))
+    sb.distant_light((float("nan"), float("nan"), float("nan")), (3.0, 3.0, 3.0), 50.0)
+    return sb
+
+
+def test_nan_directions_end_in_black_not_in_a_wild_index():
+    """A NaN direction passes `x < nodes[0] || x > nodes[n - 1]` and trips the reference's assert (math/src/spline.rs:214): the
+    oracle counts the panic and the lobe answers black; no knot index leaves the table (run under ASan by tools/cpu_asan.sh).
+    Head-on views of the sphere put mu in the table's edge intervals, where one knot of the four does not exist."""
+    img, st = OracleScene(nan_light_scene()).render(2, 2, 5, 11)
+    assert st["panics"] > 0
+    assert np.isfinite(img).all() and img.mean() > 0.003

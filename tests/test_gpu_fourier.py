@@ -85,3 +85,19 @@ WorldEnd
     gpu_ctx.upload(pbrs_amd.HostScene(ls))
     img, st = gpu_ctx.render(3, 3, 5, 2, counters=True)
     assert st["closest_rays"] == ost["closest_rays"] and same(ref, img) and ref.mean() > 0.05
+
+
+def test_nan_directions_match_the_oracle(gpu_ctx):
+    """tests/test_fourier.py::test_nan_directions_end_in_black_not_in_a_wild_index on the device: the lobe refuses a NaN
+    direction before any weight exists and skips knots outside the table, so no lane reads outside the pools."""
+    from test_fourier import nan_light_scene
+    sb = nan_light_scene()
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    for integrator, depth in (("path", 5), ("direct", 3)):
+        ref, ost = osc.render(2, 2, depth, 11, integrator=integrator)
+        img, st = gpu_ctx.render(2, 2, depth, 11, integrator=integrator, counters=True)
+        assert ost["panics"] > 0
+        assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"], integrator
+        assert same(ref, img), integrator
+        assert st["invalid_samples"] == ost["nonfinite_samples"]

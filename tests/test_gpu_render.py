@@ -543,3 +543,48 @@ def test_full_size_frames_against_oracle_windows(gpu_ctx, cfg, windows):
         ref, ost = osc.render(2, 2, c["depth"], 3, tile=(x0, y0, w, h))
         assert ost["panics"] == 0
         assert (bits(a[y0:y0 + h, x0:x0 + w]) == bits(ref)).all(), (cfg, x0, y0)
+
+
+# ---- every BASELINE config at its OWN strata and spp ---------------------------------------------------------------------------
+# The stratum of sample i is (i / strata_y, i % strata_y) (src/main.rs:198-201 generalised): sample indices beyond 15, the 16 x 16 /
+# 32 x 32 / 32 x 16 / 64 x 64 mappings and the sum of hundreds to thousands of samples per pixel in sample order are compared here
+# with the oracle bit for bit, window by window (a window is a tile of the full-size film: same camera, same RNG keys).
+
+FULL_STRATA_WINDOWS = [
+    ("c2", (480, 500, 32, 8)),    # 16 x 16 = 256 spp
+    ("c3", (300, 700, 16, 8)),    # 32 x 32 = 1024 spp: glass sphere / plastic box region
+    ("c4", (900, 600, 32, 8)),    # 32 x 16 = 512 spp on the 1 M-triangle mesh
+    ("c5", (1800, 1400, 8, 4)),   # 64 x 64 = 4096 spp, 130 instances, 64 lights
+]
+
+
+@pytest.mark.parametrize("cfg,window", FULL_STRATA_WINDOWS)
+def test_configs_at_their_own_strata_match_oracle(gpu_ctx, cfg, window):
+    sb, c = scenes.build_config(cfg)
+    sx, sy, depth = c["strata_x"], c["strata_y"], c["depth"]
+    assert (sx, sy) == {"c2": (16, 16), "c3": (32, 32), "c4": (32, 16), "c5": (64, 64)}[cfg]
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    img, st = gpu_ctx.render(sx, sy, depth, 1, tile=window, counters=True)  # automatic samples_per_pass
+    ref, ost = OracleScene(sb).render(sx, sy, depth, 1, tile=window)
+    assert ost["panics"] == 0 and ost["tlas_ties"] == 0
+    assert st["samples"] == ost["samples"] == window[2] * window[3] * sx * sy
+    assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert (bits(img) == bits(ref)).all(), cfg
+    assert float(ref.mean()) > 0.0
+    # the same window in several passes of an odd size: the pass boundaries fall inside strata rows
+    img2, _ = gpu_ctx.render(sx, sy, depth, 1, tile=window, samples_per_pass=103)
+    assert (bits(img2) == bits(ref)).all(), cfg
+
+
+def test_c4_at_512_spp_in_chunk_ordered_passes(gpu_ctx):
+    """C4 at its 32 x 16 strata on a tile of more than one 4096-pixel chunk (the second one partial), in passes of the size the
+    full frame gets (K = 103): slot order = chunk, sample index, pixel in 8 x 8 blocks (kernels.h, sample_of_slot) — every
+    sample must still land in its own pixel's sum, in sample order."""
+    sb, c = scenes.build_config("c4")
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    tile = (840, 560, 128, 40)  # 5120 pixels: chunks of 4096 + 1024
+    img, st = gpu_ctx.render(c["strata_x"], c["strata_y"], c["depth"], 1, tile=tile, samples_per_pass=103, counters=True)
+    assert st["passes"] == 5
+    ref, ost = OracleScene(sb).render(c["strata_x"], c["strata_y"], c["depth"], 1, tile=tile)
+    assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert (bits(img) == bits(ref)).all()

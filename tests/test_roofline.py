@@ -8,11 +8,16 @@ COUNTS = {"closest_rays": 1000, "tlas_nodes": 4000, "blas_nodes": 30000, "instan
 TIMES = {"ms_extend": 2.0, "ms_shadow": 1.0, "ms_shade": 1.5, "launches_extend": 2, "launches_shadow": 2, "launches_shade": 2}
 
 
-def test_queue_and_scene_bytes_follow_the_survey_table():
+def test_queue_bytes_follow_the_record_layout_and_scene_bytes_the_survey_table():
+    """Queue/state bytes: the 16-byte records the kernels move (device/kernels.h PathState) — 48 B per closest ray (two ray vectors
+    read, the hit record written), 44 B per shadow ray, 192 B per shade event — not the column layout SURVEY.md §8(d) sketched
+    (52 / 68 / 320 B), which would flatter `achieved`.  Scene bytes: §8(d)'s per-visit figures."""
     rep = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30)
-    assert rep["extend"]["queue_state_bytes_per_launch"] == 52 * 1000 / 2
-    assert rep["shadow"]["queue_state_bytes_per_launch"] == 68 * 600 / 2
-    assert rep["shade"]["queue_state_bytes_per_launch"] == 320 * 900 / 2 and rep["shade"]["scene_bytes_per_launch"] == 0
+    assert rep["extend"]["queue_state_bytes_per_launch"] == 48 * 1000 / 2
+    assert rep["shadow"]["queue_state_bytes_per_launch"] == 44 * 600 / 2
+    assert rep["shade"]["queue_state_bytes_per_launch"] == 192 * 900 / 2 and rep["shade"]["scene_bytes_per_launch"] == 0
+    assert roofline.SURVEY_8D == {"closest_ray": 52, "shadow_ray": 68, "shade_event": 320, "sample": 36}
+    assert rep["extend"]["frac_measured"] is None  # no traffic file: nothing measured to put beside the model
     assert rep["extend"]["scene_bytes_per_launch"] == (32 * 34000 + 64 * 2000 + 48 * 900 + 48 * 8000 + 60 * 700 + 16 * 10) / 2
     # no traffic file: misses count as zero and the report says so
     assert rep["extend"]["scene_miss_bytes_per_launch"] == 0 and "unmeasured" in rep["extend"]["scene_miss_source"]
@@ -61,3 +66,28 @@ def test_vector_issue_share_from_the_sq_pass():
     assert e["valu_insts_per_launch"] == 1.2e6 and e["valu_lanes_active"] == 40.0
     assert e["valu_issue_frac"] == 1.2e6 * 4 / (1024 * 1.0e-3 * 2.4e9)  # 2.0 ms over 2 launches
     assert "valu_issue_frac" not in rep["shade"] and "valu_issue_frac" not in rep["shadow"]  # no SQ figures: not reported
+
+
+def test_measured_fraction_bound_and_the_new_key_names():
+    """frac_measured = measured traffic / time / peak beside the model fraction; l2_fabric_* keys (the counters include
+    Infinity-Cache hits) are read like the hbm_* keys of older files; the bound is valu_issue where issue exceeds the HBM share."""
+    doc = {"geometry": {"frames": 1}, "kernels": {"k_extend<false, 13u>": {"launches": 2, "l2_fabric_total": 4.0e6, "valu_insts": 1.2e6, "valu_lanes_active": 40.0},
+                                                    "k_shade<0u, false, 3u>": {"launches": 2, "l2_fabric_total": 8.0e6}}}
+    rep = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30, traffic_doc=doc)
+    e = rep["extend"]
+    assert e["traffic_bytes_per_launch"] == 4.0e6
+    assert e["frac_measured"] == 4.0e6 / 1.0e-3 / 1e9 / roofline.HBM_PEAK_GBS
+    assert roofline.bound_of(e) == "valu_issue" and roofline.bound_of(rep["shade"]) == "hbm"
+
+
+def test_source_hash_follows_the_kernel_sources(tmp_path):
+    import os
+    (tmp_path / "pbrs_amd" / "csrc" / "device").mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    (tmp_path / "pbrs_amd" / "csrc" / "device" / "k.h").write_text("a")
+    (tmp_path / "include" / "x.h").write_text("b")
+    h0 = roofline.source_hash(str(tmp_path))
+    assert h0 == roofline.source_hash(str(tmp_path)) and len(h0) == 16
+    (tmp_path / "pbrs_amd" / "csrc" / "device" / "k.h").write_text("a ")
+    assert roofline.source_hash(str(tmp_path)) != h0
+    assert roofline.source_hash() == roofline.source_hash(os.path.dirname(os.path.dirname(os.path.abspath(roofline.__file__))))

@@ -21,7 +21,7 @@ def main():
     import torch
 
     import pbrs_amd
-    from pbrs_amd import scenes
+    from pbrs_amd import roofline, scenes
     sb, cfg = scenes.build_config(a.config)
     if a.strata:
         cfg["strata_x"], cfg["strata_y"] = a.strata
@@ -36,7 +36,9 @@ def main():
     spp = cfg["strata_x"] * cfg["strata_y"]
     print(json.dumps({"config": a.config, "pixels": cfg["width"] * cfg["height"], "spp": spp, "passes": st["passes"],
                       "samples_per_pass": -(-spp // st["passes"]), "frames": a.frames + (0 if a.no_warm else 1),
-                      "stages_ms": {k: v for k, v in st.items() if k.startswith("ms_")}, "scene_bytes": hs.nbytes}))
+                      "stages_ms": {k: v for k, v in st.items() if k.startswith("ms_")}, "scene_bytes": hs.nbytes,
+                      # what the counters of this run were measured on (bench.py quotes them only for the same sources)
+                      "source_hash": roofline.source_hash(), "git_head": os.environ.get("PBRS_GIT_HEAD", "unknown")}))
     ctx.close()
 
 

@@ -1,4 +1,4 @@
-"""Turns rocprofv3 TCC counter passes (tools/pmc_summary.py outputs) into HBM traffic per launch per kernel.
+"""Turns rocprofv3 TCC counter passes (tools/pmc_summary.py outputs) into memory-side (L2 -> fabric) traffic per launch per kernel.
 
     python tools/traffic_from_pmc.py GEOMETRY.json fetch.txt write.txt [rdreq_sizes.txt [wrreq.txt [sq_wave_cycles.txt]]]
 
@@ -8,7 +8,7 @@ FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so it i
 doubling is calibrated on k_accumulate (a pure coalesced stream of known size) and recorded.  Because the guide calls
 other access widths uncalibrated, the optional third pass gives an independent figure for every kernel from the
 request-size counters of gfx950 (TCC_EA0_RDREQ_{32B,64B,128B}): read bytes = 32 n32 + 64 n64 + 128 n128, with requests
-of no recorded size counted at 64 B — reported as hbm_read_by_request_size next to hbm_read; bench.py uses the larger of
+of no recorded size counted at 64 B — reported as l2_fabric_read_by_request_size next to l2_fabric_read; bench.py uses the larger of
 the two so that a roofline fraction is never flattered.  The optional sixth file (the SQ pass) adds, per kernel, the vector
 instructions of a launch and the lanes active in them: what bench.py turns into the share of the chip's vector issue slots a
 kernel uses (a wave64 instruction occupies a 16-lane SIMD for 4 cycles) — the bound of the kernels HBM does not bind.
@@ -38,7 +38,9 @@ wr = parse(sys.argv[5]) if len(sys.argv) > 5 else {}
 sq = parse(sys.argv[6]) if len(sys.argv) > 6 else {}
 n_pixels = geo["pixels"]
 n_slots = n_pixels * geo["samples_per_pass"]
-res = {"unit": "bytes per launch", "geometry": geo, "kernels": {}}
+res = {"unit": "bytes per launch", "geometry": geo, "source_hash": geo.get("source_hash"), "git_head": geo.get("git_head"),
+       "note": "l2_fabric_* = bytes of the L2's memory-side requests (FETCH_SIZE / WRITE_SIZE / TCC_EA0_*): they INCLUDE Infinity-Cache "
+               "hits, so for a scene that fits the 256 MiB Infinity Cache they are an upper bound of true HBM traffic", "kernels": {}}
 acc = fetch.get("k_accumulate")
 if acc:
     known_read = float(geo.get("accumulate_read_bytes_per_slot", 12)) * n_slots + 12.0 * n_pixels
@@ -49,14 +51,14 @@ for k in fetch:
     d = fetch[k]["dispatches"]
     rd = fetch[k]["FETCH_SIZE"] * 1024 / d * 2.0   # guide: FETCH_SIZE = half the streamed bytes on gfx950
     wb = write[k]["WRITE_SIZE"] * 1024 / d
-    row = {"launches": d, "hbm_read": rd, "hbm_write": wb}
+    row = {"launches": d, "l2_fabric_read": rd, "l2_fabric_write": wb}
     if k in sizes:
         s, ds = sizes[k], sizes[k]["dispatches"]
         n32, n64, n128 = s.get("TCC_EA0_RDREQ_32B_sum", 0.0), s.get("TCC_EA0_RDREQ_64B_sum", 0.0), s.get("TCC_EA0_RDREQ_128B_sum", 0.0)
         rest = max(s.get("TCC_EA0_RDREQ_sum", 0.0) - n32 - n64 - n128, 0.0)
-        row["hbm_read_by_request_size"] = (32 * n32 + 64 * (n64 + rest) + 128 * n128) / ds
+        row["l2_fabric_read_by_request_size"] = (32 * n32 + 64 * (n64 + rest) + 128 * n128) / ds
         row["read_requests"] = {"32B": n32 / ds, "64B": n64 / ds, "128B": n128 / ds, "unsized": rest / ds}
-        rd = max(rd, row["hbm_read_by_request_size"])
+        rd = max(rd, row["l2_fabric_read_by_request_size"])
     if k in wr:
         s, ds = wr[k], wr[k]["dispatches"]
         row["write_requests"] = {"all": s.get("TCC_EA0_WRREQ_sum", 0.0) / ds, "64B": s.get("TCC_EA0_WRREQ_64B_sum", 0.0) / ds}
@@ -69,6 +71,6 @@ for k in fetch:
         row["valu_lanes_active"] = q.get("SQ_THREAD_CYCLES_VALU", 0.0) / q["SQ_INSTS_VALU"]  # of 64
         if q.get("SQ_WAVE_CYCLES"):
             row["wave_wait_share"] = q.get("SQ_WAIT_INST_ANY", 0.0) / q["SQ_WAVE_CYCLES"]  # of a wave's cycles spent waiting on an instruction's operands
-    row["hbm_total"] = rd + wb
+    row["l2_fabric_total"] = rd + wb
     res["kernels"][k] = row
 print(json.dumps(res, indent=1))
