@@ -364,6 +364,64 @@ PN_FN void pn_sincos_f64(double x, double* s, double* c) {
 
 PN_FN float pn_to_radians(float deg) { return deg * (PN_PI / 180.0f); }
 
+/* ---- f64 pieces of radiometry/src/spectrum.rs:3-25 (Planck's law in f64: `powi(2)`, `powi(5)`, `exp_m1`) --------------------
+ * f64::powi = compiler-rt __powidf2: square-and-multiply, LSB first (as pn_powi). */
+PN_FN double pn_powi_f64(double a, int b) {
+    int recip = b < 0;
+    double r = 1.0;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0 / r : r;
+}
+/* f64::exp / f64::exp_m1: the double-precision Cephes kernels (2-part ln2 reduction, Pade-type rational in x^2); the
+ * platform libm they stand for is unpinned by the reference, as for f32.  Only IEEE f64 + - * / and integer ops. */
+PN_FN double pn_exp_f64(double x) {
+    if (x != x) return x;
+    if (x > 709.782712893384) return (double)pn_inf();
+    if (x < -745.13321910194122) return 0.0;
+    double fl = 1.4426950408889634073599 * x + 0.5;
+    int64_t n = (int64_t)fl;
+    if ((double)n > fl) n -= 1; /* floor */
+    const double px0 = (double)n;
+    x -= px0 * 6.93145751953125e-1;
+    x -= px0 * 1.42860682030941723212e-6;
+    const double xx = x * x;
+    double p = 1.26177193074810590878e-4;
+    p = p * xx + 3.02994407707441961300e-2;
+    p = p * xx + 9.99999999999999999910e-1;
+    p = x * p;
+    double q = 3.00198505138664455042e-6;
+    q = q * xx + 2.52448340349684104192e-3;
+    q = q * xx + 2.27265548208155028766e-1;
+    q = q * xx + 2.00000000000000000009e0;
+    double r = 1.0 + 2.0 * (p / (q - p));
+    /* ldexp in two steps so that results near the ends of the range pass through normal scale factors */
+    int64_t n1 = n / 2, n2 = n - n1;
+    union { uint64_t u; double d; } s1, s2;
+    s1.u = (uint64_t)(n1 + 1023) << 52;
+    s2.u = (uint64_t)(n2 + 1023) << 52;
+    return r * s1.d * s2.d;
+}
+PN_FN double pn_expm1_f64(double x) {
+    if (x != x) return x;
+    if (x < -0.5 || x > 0.5) return pn_exp_f64(x) - 1.0;
+    const double xx = x * x;
+    double p = 1.2617719307481059087798e-4;
+    p = p * xx + 3.0299440770744196129956e-2;
+    p = p * xx + 9.9999999999999999991025e-1;
+    double r = x * p;
+    double q = 3.0019850513866445504159e-6;
+    q = q * xx + 2.5244834034968410419224e-3;
+    q = q * xx + 2.2726554820815502876593e-1;
+    q = q * xx + 2.0000000000000000000897e0;
+    r = r / (q - r);
+    return r + r;
+}
+
 /* ---- RNG contract --------------------------------------------------
  * The reference draws from an unseedable thread_rng (ChaCha12); the north-star asks for fixed
  * per-pixel seeds, so the stream is a new contract: one PCG32 (XSH-RR 64/32) generator per camera

@@ -62,6 +62,8 @@ def lib():
         L.oracle_camera_rays.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_uint64, C.c_void_p, C.c_void_p]
         L.oracle_numeric_eval.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_rng_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_temperature_to_color.argtypes = [C.c_float, C.c_void_p]
+        L.oracle_spd_to_color.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_selftest.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32]
         L.oracle_selftest_count.restype = C.c_uint32
         L.oracle_selftest_name.restype = C.c_char_p
@@ -84,6 +86,22 @@ def numeric_eval(fn, x, y=None):
     rc = lib().oracle_numeric_eval(NUMERIC_FNS[fn], x.size, x.ctypes.data, yp, out.ctypes.data)
     assert rc == 0
     return out
+
+
+def temperature_to_color(kelvin):
+    """radiometry/src/spectrum.rs:38-55 -> (rgb, panics)."""
+    out = np.empty(3, dtype=np.float32)
+    panics = lib().oracle_temperature_to_color(float(kelvin), out.ctypes.data)
+    return out, panics
+
+
+def spd_to_color(lambdas_nm, values):
+    """sampled_spectrum_to_color (radiometry/src/spectrum.rs:57-70) over (lambda, value) samples -> (rgb, panics)."""
+    lam = np.ascontiguousarray(lambdas_nm, dtype=np.float32)
+    val = np.ascontiguousarray(values, dtype=np.float32)
+    out = np.empty(3, dtype=np.float32)
+    panics = lib().oracle_spd_to_color(len(lam), lam.ctypes.data, val.ctypes.data, out.ctypes.data)
+    return out, panics
 
 
 def rng_stream(seed, pixel, sample, n):

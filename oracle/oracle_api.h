@@ -69,6 +69,10 @@ int oracle_camera_rays(const oracle_scene*, uint32_t x0, uint32_t y0, uint32_t w
 int oracle_texture_value(const pbrs_texture_spec* tex, uint32_t n, const float* uv, const float* pos, float* rgb_out);
 int oracle_env_eval(const oracle_scene*, uint32_t n, const float* dirs, float* rgb_out);
 int oracle_numeric_eval(uint32_t fn, uint32_t n, const float* x, const float* y, float* out);
+/* radiometry/src/spectrum.rs: temperature_to_color(kelvin) (:38-55) and sampled_spectrum_to_color over n (lambda, value) samples
+ * (:57-70).  Return the number of panic sites reached. */
+int oracle_temperature_to_color(float kelvin, float* rgb_out);
+int oracle_spd_to_color(uint32_t n, const float* lambdas_nm, const float* values, float* rgb_out);
 int oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
 
 /* oracle/selftest.cpp: the reference's own known-answer tests, transcribed.  Returns the number of

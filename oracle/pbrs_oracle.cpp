@@ -713,6 +713,24 @@ int oracle_numeric_eval(uint32_t fn, uint32_t n, const float* x, const float* y,
     }
     return 0;
 }
+int oracle_temperature_to_color(float kelvin, float* rgb_out) {
+    Diag d;
+    g_diag = &d;
+    Color c = temperature_to_color(kelvin);
+    g_diag = nullptr;
+    rgb_out[0] = c.r, rgb_out[1] = c.g, rgb_out[2] = c.b;
+    return (int)d.panics;
+}
+int oracle_spd_to_color(uint32_t n, const float* lambdas_nm, const float* values, float* rgb_out) {
+    Diag d;
+    g_diag = &d;
+    std::vector<std::pair<float, float>> samples;
+    for (uint32_t i = 0; i < n; ++i) samples.push_back({lambdas_nm[i], values[i]});
+    Color c = sampled_spectrum_to_color(samples);
+    g_diag = nullptr;
+    rgb_out[0] = c.r, rgb_out[1] = c.g, rgb_out[2] = c.b;
+    return (int)d.panics;
+}
 int oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out) {
     uint64_t s = pn_rng_init(seed, pixel, sample);
     for (uint32_t i = 0; i < n; ++i) out[i] = pn_rng_f32(&s);

@@ -296,4 +296,17 @@ struct Scene {
 };
 std::unique_ptr<Scene> scene_from_spec(const pbrs_scene_spec& spec);
 
+// ---- radiometry/src/spectrum.rs:3-70, math/src/spline.rs:11-158 (ref_spectrum.cpp): load-time colour conversions ----------
+std::vector<float> blackbody(float kelvin, const std::vector<float>& lambdas_nm);
+std::vector<float> blackbody_normalized(float kelvin, const std::vector<float>& lambdas_nm);
+Color temperature_to_color(float kelvin);
+bool tridiagonal(const std::vector<float>& a, const std::vector<float>& b, const std::vector<float>& c, const std::vector<float>& rhs, std::vector<float>* x_out);
+bool cubic_spline_zero_hess(const std::vector<std::pair<float, float>>& xs_and_ys, std::vector<float>* m_out);
+struct CubicSpline {
+    std::vector<float> m, xs, ys;
+    static bool from_samples(const std::vector<std::pair<float, float>>& xs_and_ys, CubicSpline* out);
+    float evaluate(float at) const;
+};
+Color sampled_spectrum_to_color(std::vector<std::pair<float, float>> lambdas_and_values);
+
 }  // namespace ref

@@ -594,6 +594,47 @@ void mf_refl_test() {
     CHECK(responses > 0, "no sample of the grid had a positive density");
 }
 
+// radiometry/src/spectrum.rs:471-496 test_temperature_to_color: five temperatures, each channel within 3e-3
+void temperature_to_color_test() {
+    const float temperatures[5] = {2700.0f, 3500.0f, 4500.0f, 5000.0f, 6500.0f};
+    const Color true_colors[5] = {Color{0.533494f, 0.221571f, 0.052902f}, Color{1.007905f, 0.574979f, 0.261424f}, Color{1.215729f, 0.883807f, 0.610254f},
+                                  Color{1.190014f, 0.942058f, 0.747937f}, Color{0.922219f, 0.869496f, 0.915217f}};
+    for (int i = 0; i < 5; ++i) {
+        Color c = temperature_to_color(temperatures[i]);
+        const float THRESHOLD = 3e-3f;
+        CHECK(pn_abs(c.r - true_colors[i].r) <= THRESHOLD && pn_abs(c.g - true_colors[i].g) <= THRESHOLD && pn_abs(c.b - true_colors[i].b) <= THRESHOLD,
+              "%g K: (%g, %g, %g), expected (%g, %g, %g)", temperatures[i], c.r, c.g, c.b, true_colors[i].r, true_colors[i].g, true_colors[i].b);
+    }
+}
+// math/src/spline.rs:314-331 tridiagonal_test
+void tridiagonal_test() {
+    std::vector<float> a(7, 1.0f), b(7, 1.5f), c(7, 1.0f), rhs(7, 7.0f), x;
+    rhs[0] = 5.0f;
+    rhs[6] = 5.0f;
+    CHECK(tridiagonal(a, b, c, rhs, &x) && x.size() == 7, "tridiagonal refused a 7 x 7 system");
+    float total_square_error = 0.0f;
+    for (size_t i = 0; i < x.size(); ++i) total_square_error += pn_powi(x[i] - 2.0f, 2);
+    CHECK(total_square_error <= 1e-6f, "sum of squared errors %g", total_square_error);
+}
+// math/src/spline.rs:333-345 cubic_spline_solve_test and :347-360 cubic_spline_eval_test
+void cubic_spline_test() {
+    const float x[5] = {0.2f, 0.4f, 0.6f, 0.8f, 1.0f}, y[5] = {0.97986f, 0.91777f, 0.80803f, 0.63860f, 0.38437f};
+    std::vector<std::pair<float, float>> pairs;
+    for (int i = 0; i < 5; ++i) pairs.push_back({x[i], y[i]});
+    std::vector<float> actual_m;
+    CHECK(cubic_spline_zero_hess(pairs, &actual_m) && actual_m.size() == 3, "cubic_spline_zero_hess refused five samples");
+    const float expected_m[3] = {-1.5021f, -1.1390f, -2.8952f};
+    float total_error_squared = 0.0f;
+    for (size_t i = 0; i < actual_m.size() && i < 3; ++i) total_error_squared += pn_powi(expected_m[i] - actual_m[i], 2);
+    CHECK(total_error_squared <= 1e-6f, "second derivatives off: %g", total_error_squared);
+    CubicSpline spline;
+    CHECK(CubicSpline::from_samples(pairs, &spline), "from_samples refused five samples");
+    const float at[4] = {0.3f, 0.5f, 0.7f, 0.9f}, want[4] = {0.9526f, 0.8695f, 0.7334f, 0.5187f};
+    for (int i = 0; i < 4; ++i) CHECK(pn_abs(spline.evaluate(at[i]) - want[i]) <= 3e-5f, "spline(%g) = %g, expected %g", at[i], spline.evaluate(at[i]), want[i]);
+    // outside the samples the end values are returned (:41-45)
+    CHECK(spline.evaluate(0.1f) == y[0] && spline.evaluate(1.5f) == y[4], "values outside the domain");
+}
+
 // math/src/spline.rs:384-408 test_find_interval
 void find_interval_test() {
     const int array[8] = {16, 21, 32, 43, 55, 62, 73, 82};
@@ -710,6 +751,9 @@ const Entry kTests[] = {
     {"observe_sphere_sample_towards", observe_sphere_sample_towards},
     {"lambertian_test", lambertian_test},
     {"mf_refl_test", mf_refl_test},
+    {"temperature_to_color_test", temperature_to_color_test},
+    {"tridiagonal_test", tridiagonal_test},
+    {"cubic_spline_test", cubic_spline_test},
     {"find_interval_test", find_interval_test},
     {"catmull_test", catmull_test},
     {"fourier_sum_test", fourier_sum_test},

@@ -2,7 +2,7 @@
 device from one thread each (the reference's rayon workers share `&Scene`, src/main.rs:219-224).  Nothing a
 context does may depend on what another context of the process holds: in particular the dynamic-LDS limit of the traversal
 kernels is per-function state of the process and is raised once per device to the cap, not per uploaded scene."""
-import os
+import ctypes
 import threading
 
 import numpy as np
@@ -35,15 +35,23 @@ def test_two_contexts_with_different_stack_depths_interleaved():
             i2, _ = b.render(2, 2, c2["depth"], 7, tile=w2)
             assert (bits(i4) == bits(ref4)).all()
             assert (bits(i2) == bits(ref2)).all()
-        # asynchronous renders of both contexts in flight at once, each on its own stream
-        import torch
-        o4 = torch.empty((8, 64, 3), dtype=torch.float32, device="cuda:0")
-        o2 = torch.empty((8, 64, 3), dtype=torch.float32, device="cuda:0")
-        a.render_device(o4.data_ptr(), 2, 2, c4["depth"], 7, tile=w4)
-        b.render_device(o2.data_ptr(), 2, 2, c2["depth"], 7, tile=w2)
-        a.collect_stats()
-        b.collect_stats()
-        assert (bits(o4.cpu().numpy()) == bits(ref4)).all() and (bits(o2.cpu().numpy()) == bits(ref2)).all()
+        # asynchronous renders of both contexts in flight at once, each on its own stream, into caller-owned device memory
+        hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself runs on
+        nbytes = 8 * 64 * 3 * 4
+        o4, o2 = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(o4), ctypes.c_size_t(nbytes)) == 0 and hip.hipMalloc(ctypes.byref(o2), ctypes.c_size_t(nbytes)) == 0
+        try:
+            a.render_device(o4.value, 2, 2, c4["depth"], 7, tile=w4)
+            b.render_device(o2.value, 2, 2, c2["depth"], 7, tile=w2)
+            a.collect_stats()  # waits for the context's own stream: the output is valid from here on
+            b.collect_stats()
+            h4, h2 = np.empty((8, 64, 3), dtype=np.float32), np.empty((8, 64, 3), dtype=np.float32)
+            assert hip.hipMemcpy(ctypes.c_void_p(h4.ctypes.data), o4, ctypes.c_size_t(nbytes), 2) == 0  # hipMemcpyDeviceToHost
+            assert hip.hipMemcpy(ctypes.c_void_p(h2.ctypes.data), o2, ctypes.c_size_t(nbytes), 2) == 0
+            assert (bits(h4) == bits(ref4)).all() and (bits(h2) == bits(ref2)).all()
+        finally:
+            hip.hipFree(o4)
+            hip.hipFree(o2)
     finally:
         a.close()
         b.close()

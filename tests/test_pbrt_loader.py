@@ -205,10 +205,85 @@ WorldEnd
     ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "fourier" WorldEnd', "bsdffile"),
     ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Shape "sphere" WorldEnd', "material"),
     ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Bogus WorldEnd', "token"),
-    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "matte" "blackbody Kd" [6500 1] Shape "sphere" WorldEnd', "spectral"),
+    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "matte" "spectrum Kd" [400 1 500 1 600 1] Shape "sphere" WorldEnd', "unimplemented"),
+    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "metal" "spectrum eta" "missing.spd" Shape "sphere" WorldEnd', "SPD file"),
+    ('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin Material "matte" Shape "loopsubdiv" WorldEnd', "implemented upstream"),
 ])
 def test_unsupported_input_is_an_error_not_an_abort(tmp_path, text, needle):
     (tmp_path / "bad.pbrt").write_text(text + "\n")
     with pytest.raises(pbrs_amd.PbrsError) as e:
         pbrs_amd.load_pbrt(str(tmp_path / "bad.pbrt"))
     assert needle.lower() in str(e.value).lower()
+
+
+# ---- spectra: `.spd` metals and blackbody colours (scene/src/loader.rs:548-570, :763, :858-879 -> radiometry/src/spectrum.rs) ------
+
+GOLD_ETA = [(298.75705, 1.795), (302.400421, 1.812), (306.133759, 1.822625), (309.960449, 1.83), (360.0, 1.716), (400.0, 1.658), (450.0, 1.3831),
+            (500.0, 0.9164), (550.0, 0.3321), (600.0, 0.2493), (650.0, 0.1676), (700.0, 0.1610), (750.0, 0.1660), (800.0, 0.1808), (880.0, 0.2100)]
+GOLD_K = [(298.75705, 1.920375), (302.400421, 1.92), (306.133759, 1.918875), (309.960449, 1.916), (360.0, 1.87), (400.0, 1.956), (450.0, 1.83),
+          (500.0, 1.84), (550.0, 2.324), (600.0, 2.863), (650.0, 3.471), (700.0, 3.95), (750.0, 4.38), (800.0, 5.06), (880.0, 5.88)]
+
+
+def write_spd(path, samples, shuffle=False):
+    rows = list(samples)
+    if shuffle:
+        rows = rows[1::2] + rows[0::2]  # sampled_spectrum_to_color sorts by wavelength
+    path.write_text("# wavelength (nm)  value\n" + "".join(f"{lam!r} {v!r}\n" for lam, v in rows))
+
+
+def test_spd_metals_and_blackbody_colours_match_the_oracle(tmp_path):
+    """The loader's colours come from the host library's restatement of radiometry/src/spectrum.rs + math/src/spline.rs; the oracle
+    restates them on its own (oracle/ref_spectrum.cpp, pinned by the reference's test_temperature_to_color / spline vectors):
+    the two must agree bit for bit, and the loaded scene must be the scene built through the spec with those colours."""
+    from oracle import binding
+    write_spd(tmp_path / "Au.eta.spd", GOLD_ETA)
+    write_spd(tmp_path / "Au.k.spd", GOLD_K, shuffle=True)
+    (tmp_path / "s.pbrt").write_text("""
+LookAt 0 2 -6 0 1 0 0 1 0  Camera "perspective" "float fov" [45]  Film "image" "integer xresolution" [48] "integer yresolution" [32]
+WorldBegin
+AttributeBegin AreaLightSource "diffuse" "blackbody L" [6500 2.5] Translate 0 5 0 Shape "sphere" "float radius" [0.7] AttributeEnd
+LightSource "point" "point from" [3 4 -3] "blackbody L" [2700 30]
+AttributeBegin Material "metal" "spectrum eta" "Au.eta.spd" "spectrum k" "Au.k.spd" "float roughness" [0.05] Translate 0 1 0 Shape "sphere" "float radius" [1] AttributeEnd
+AttributeBegin Material "matte" "rgb Kd" [.5 .5 .5] Translate 0 -100 0 Shape "sphere" "float radius" [100] AttributeEnd
+WorldEnd
+""")
+    ls = pbrs_amd.load_pbrt(str(tmp_path / "s.pbrt"))
+    s = ls.build()
+    eta, p0 = binding.spd_to_color(*zip(*GOLD_ETA))
+    k, p1 = binding.spd_to_color(*zip(*GOLD_K))
+    warm, p2 = binding.temperature_to_color(2700.0)
+    day, p3 = binding.temperature_to_color(6500.0)
+    assert p0 == p1 == p2 == p3 == 0
+    metal = [s.materials[i] for i in range(s.n_materials) if s.materials[i].kind == spec.MTL_METAL][0]
+    assert (np.array(list(metal.p)[:3], dtype=f32).view(np.uint32) == eta.view(np.uint32)).all()
+    assert (np.array(list(metal.p)[3:6], dtype=f32).view(np.uint32) == k.view(np.uint32)).all()
+    assert 0.1 < eta[0] < 0.3 and eta[2] > 1.0 and k[0] > k[2], "gold: little red refraction, strong red absorption"
+    assert (np.array(list(s.area_lights[0].emit), dtype=f32).view(np.uint32) == (day * f32(2.5)).view(np.uint32)).all()
+    assert (np.array(list(s.delta_lights[0].color), dtype=f32).view(np.uint32) == (warm * f32(30.0)).view(np.uint32)).all()
+    # the same scene assembled through the spec with the oracle's colours renders the same image
+    sb = SceneBuilder()
+    e = tuple(float(x) for x in day * f32(2.5))
+    sb.instance(sb.sphere((0, 0, 0), 0.7), sb.diffuse_light(e), Transform.translater((0, 5, 0)))
+    sb.area_light(e, sb.sphere((0, 5, 0), 0.7))
+    sb.point_light((3, 4, -3), tuple(float(x) for x in warm * f32(30.0)))
+    sb.instance(sb.sphere((0, 0, 0), 1.0), sb.metal(tuple(float(x) for x in eta), tuple(float(x) for x in k), 0.05), Transform.translater((0, 1, 0)))
+    sb.instance(sb.sphere((0, 0, 0), 100.0), sb.lambertian((.5, .5, .5)), Transform.translater((0, -100, 0)))
+    sb.set_camera(48, 32, deg(45.0), (0, 2, -6), (0, 1, 0))
+    a, sa = OracleScene(ls).render(2, 2, 5, 3)
+    b, sb_ = OracleScene(sb).render(2, 2, 5, 3)
+    assert sa["closest_rays"] == sb_["closest_rays"]
+    assert (a.view(np.uint32) == b.view(np.uint32)).all() and a.mean() > 0.01
+
+
+@pytest.mark.parametrize("content,needle", [("400 1\n500 2\n600 3\n", "four samples"), ("400 1\n\n500 2\n600 3\n700 1\n", "not `lambda value`"),
+                                            ("400  1\n500 2\n600 3\n700 1\n", "not `lambda value`"), ("400\n500 2\n600 3\n700 1\n", "fewer than two"),
+                                            ("nan 1\n500 2\n600 3\n700 1\n", "NaN")])
+def test_malformed_spd_files_are_errors(tmp_path, content, needle):
+    """Where the reference panics — `tridiagonal` on fewer than four samples, `.parse::<f32>().unwrap()` on an empty piece, the
+    `numbers.len() >= 2` assert, `partial_cmp().unwrap()` on a NaN wavelength — the loader reports an error."""
+    (tmp_path / "x.spd").write_text(content)
+    (tmp_path / "s.pbrt").write_text('Camera "perspective" Film "image" "integer xresolution" [8] "integer yresolution" [8] WorldBegin '
+                                     'Material "metal" "spectrum eta" "x.spd" Shape "sphere" WorldEnd\n')
+    with pytest.raises(pbrs_amd.PbrsError) as e:
+        pbrs_amd.load_pbrt(str(tmp_path / "s.pbrt"))
+    assert needle in str(e.value)
