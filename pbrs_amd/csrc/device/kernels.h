@@ -44,7 +44,7 @@ struct PathState {
     float4* nee[3];   // [slot]: c1.xyz, 1 / light_pdf | c2.xyz, post factor | beta at the time of the estimate, -
     uint8_t* occ[2];  // [slot], written by k_shadow: 1 = the ray is occluded
 };
-#define PBRS_STATE_BYTES_PER_PATH (2u * 48u + 16u + 4u + 1u + 16u + 2u * 48u + 48u + 2u + 4u)  // records above + the nee queue entry
+#define PBRS_STATE_BYTES_PER_PATH (2u * 48u + 16u + 4u + 1u + 16u + 2u * 48u + 48u + 2u + 4u + 8u)  // records above + the nee queue entry + two slow-list entries
 
 struct RenderConst {
     pbrs_camera cam;
@@ -345,12 +345,51 @@ PD uint32_t wave_fetch(WaveWork& w, bool need, uint32_t* heads, uint32_t n) {
     }
     return idx;
 }
+// Rays a wide-walk kernel cannot take (traverse.h, PBRS_WALK_SLOW) go, whole, into a list that the binary-walk kernel of the
+// same stage works off right after it: one atomic per wave and batch.
+PD void wave_append_slow(bool slow, uint32_t item, uint32_t* list, uint32_t* count) {
+    const uint64_t m = __ballot(slow);
+    if (m == 0) return;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (slow) list[base + lane_prefix(m)] = item;
+}
+#ifndef PBRS_WIDE_EXTEND_WAVES  // min waves per SIMD asked of the register allocator for the wide-walk kernels
+#define PBRS_WIDE_EXTEND_WAVES 5
+#endif
+#ifndef PBRS_WIDE_SHADOW_WAVES
+#define PBRS_WIDE_SHADOW_WAVES 5
+#endif
+#ifndef PBRS_WIDE_NODE_STEPS  // node steps per loop round of the wide walks in scenes with long walks
+#define PBRS_WIDE_NODE_STEPS 2u
+#endif
+template <bool WIDE, bool STATS, uint32_t FEAT>
+struct ClosestSel {
+    typedef ClosestWalkW<FEAT> type;
+};
+template <bool STATS, uint32_t FEAT>
+struct ClosestSel<false, STATS, FEAT> {
+    typedef ClosestWalk<STATS, FEAT> type;
+};
+template <bool WIDE, bool STATS, uint32_t FEAT>
+struct AnySel {
+    typedef AnyWalkW<FEAT> type;
+};
+template <bool STATS, uint32_t FEAT>
+struct AnySel<false, STATS, FEAT> {
+    typedef AnyWalk<STATS, FEAT> type;
+};
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
 // handed a new ray at the next refill, the walks of the other lanes continue where they were.
+// `indirect` (binary-walk kernels working off a slow list): the queue positions to trace, `count` of them.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES) k_extend(DevScene S, PathState st, uint32_t set, const uint32_t* count, uint32_t n_direct,
-                                               uint32_t* next, GlobalCounters* gc) {
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_EXTEND_WAVES : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES)
+    k_extend(DevScene S, PathState st, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect,
+             uint32_t* slow_list, uint32_t* slow_count) {
     extern __shared__ uint32_t lds_stack[];
+    constexpr bool WIDE = !STATS && (FEAT & PBRS_FEAT_WIDE) != 0u;
     const uint32_t n = count ? *count : n_direct;
     const float4* q0 = st.q[set][0];
     const float4* q1 = st.q[set][1];
@@ -358,13 +397,17 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
-    ClosestWalk<STATS, (FEAT & PBRS_FEAT_ALL)> walk;
+    typename ClosestSel<WIDE, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
     walk.mode = PBRS_WALK_IDLE;
     uint32_t item = 0;  // queue position of the lane's ray
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
         if ((uint32_t)__popcll(live) < S.refill_below) {
+            if constexpr (WIDE) {
+                wave_append_slow(walk.mode == PBRS_WALK_SLOW, item, slow_list, slow_count);
+                if (walk.mode == PBRS_WALK_SLOW) walk.mode = PBRS_WALK_IDLE;
+            }
             if (walk.mode == PBRS_WALK_DONE) {  // finished walks are retired in batches, at refill time
                 walk.finish(cnt);  // a walk that ended inside an instance: its candidate meets the best hit here
                 const Hit& h = walk.best;
@@ -380,18 +423,28 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_SHADING_CHE
             if (work.left()) {
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
+                    if (indirect) idx = indirect[idx];
                     item = idx;
                     stk.item = idx;
                     const float4 a = q0[idx], b = q1[idx];
                     walk.start(S, xyz(a), xyz(b), pn_inf(), stk);
                     nrays++;
                 }
-                walk.scan_wave(S, cnt);
+                if constexpr (WIDE) walk.scan_wave(S, stk);
+                else walk.scan_wave(S, cnt);
                 live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
-            if (live == 0) break;
+            if (live == 0) {
+                if constexpr (WIDE) {
+                    walk.forget_reciprocals();
+                    if (__ballot(walk.mode == PBRS_WALK_SLOW || walk.mode == PBRS_WALK_DONE)) continue;  // rays that ended in the refill itself
+                }
+                break;
+            }
         }
-        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN, (FEAT & PBRS_FEAT_LONG_WALKS) ? PBRS_NODE_STEPS_LONG : 1u);
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN,
+                       (FEAT & PBRS_FEAT_LONG_WALKS) ? (WIDE ? PBRS_WIDE_NODE_STEPS : PBRS_NODE_STEPS_LONG) : 1u);
+        if constexpr (WIDE) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
 }
@@ -998,21 +1051,27 @@ __global__ void __launch_bounds__(256) k_class_scatter(PathState st, const uint3
 // ---- shadow ----------------------------------------------------------------------------------------------------
 // One work item per shadow ray (persistent, same refill scheme as k_extend); writes one occlusion byte.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : PBRS_SHADOW_WAVES) k_shadow(DevScene S, PathState st, const uint32_t* count, uint32_t* next,
-                                               GlobalCounters* gc) {
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_SHADOW_WAVES : PBRS_SHADOW_WAVES)
+    k_shadow(DevScene S, PathState st, const uint32_t* count, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect, uint32_t* slow_list,
+             uint32_t* slow_count) {
     extern __shared__ uint32_t lds_stack[];
-    const uint32_t n = count[1];  // high half of the packed (nee paths, shadow rays) counter
+    constexpr bool WIDE = !STATS && (FEAT & PBRS_FEAT_WIDE) != 0u;
+    const uint32_t n = indirect ? count[0] : count[1];  // a slow list's length, or the high half of the packed (nee paths, shadow rays) counter
     LaneStack stk{lds_stack + threadIdx.x, st.sr[0], st.sr[1], 0u};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
-    AnyWalk<STATS, (FEAT & PBRS_FEAT_ALL)> walk;
+    typename AnySel<WIDE, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
     walk.mode = PBRS_WALK_IDLE;
     uint32_t item = 0, rec = 0;
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
         if ((uint32_t)__popcll(live) < S.refill_below) {
+            if constexpr (WIDE) {
+                wave_append_slow(walk.mode == PBRS_WALK_SLOW, rec, slow_list, slow_count);
+                if (walk.mode == PBRS_WALK_SLOW) walk.mode = PBRS_WALK_IDLE;
+            }
             if (walk.mode == PBRS_WALK_DONE) {
                 const bool occluded = walk.occluded;
                 const uint32_t slot = item & PBRS_SLOT_MASK, r = item >> 31;
@@ -1033,6 +1092,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_SHADOW_WAVES) k_shadow(D
             if (work.left()) {
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
+                    if (indirect) idx = indirect[idx];
                     rec = idx;
                     stk.item = idx;
                     const float4 q0 = st.sr[0][idx], q1 = st.sr[1][idx];
@@ -1040,12 +1100,21 @@ __global__ void __launch_bounds__(256, STATS ? 3 : PBRS_SHADOW_WAVES) k_shadow(D
                     walk.start(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, stk);
                     nrays++;
                 }
-                walk.scan_wave(S, cnt);
+                if constexpr (WIDE) walk.scan_wave(S, stk);
+                else walk.scan_wave(S, cnt);
                 live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
-            if (live == 0) break;
+            if (live == 0) {
+                if constexpr (WIDE) {
+                    walk.forget_reciprocals();
+                    if (__ballot(walk.mode == PBRS_WALK_SLOW || walk.mode == PBRS_WALK_DONE)) continue;
+                }
+                break;
+            }
         }
-        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN, (FEAT & PBRS_FEAT_LONG_WALKS) ? PBRS_NODE_STEPS_LONG : 1u);
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN,
+                       (FEAT & PBRS_FEAT_LONG_WALKS) ? (WIDE ? PBRS_WIDE_NODE_STEPS : PBRS_NODE_STEPS_LONG) : 1u);
+        if constexpr (WIDE) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, 0u);
 }
@@ -1118,8 +1187,10 @@ __global__ void k_sum_bounce_counts(const uint32_t* act, const unsigned long lon
 }
 
 // ---- parity-harness kernels --------------------------------------------------------------------------------------------
+// WIDE: through the walks over four-wide nodes (the kernels the pipeline runs for scenes with a scanned TLAS), else the binary walks.
+template <bool WIDE>
 __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, const float4* origins, const float4* dirs, const float* tmax,
-                                                       pbrs_hit_record* hits, uint8_t* occluded) {
+                                                       pbrs_hit_record* hits, uint8_t* occluded, uint32_t stack_rows) {
     extern __shared__ uint32_t lds_stack[];
     LaneStack stk{lds_stack + threadIdx.x, origins, dirs, 0u};
     Cnt<false> cnt;
@@ -1137,7 +1208,8 @@ __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, 
         }
         if (hits) {
             Hit h;
-            tlas_closest<false>(S, active, o, d, t_max, stk, h, cnt);
+            if (WIDE) tlas_closest_wide(S, active, o, d, t_max, stk, h);
+            else tlas_closest<false>(S, active, o, d, t_max, stk, h, cnt);
             if (active) {
                 pbrs_hit_record r;
                 r.t = h.t;
@@ -1150,7 +1222,7 @@ __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, 
             }
         }
         if (occluded) {
-            const bool occ = tlas_any<false>(S, active, o, d, t_max, stk, cnt);
+            const bool occ = WIDE ? tlas_any_wide(S, active, o, d, t_max, stk) : tlas_any<false>(S, active, o, d, t_max, stk, cnt);
             if (active) occluded[i] = occ ? 1 : 0;
         }
     }

@@ -12,6 +12,7 @@
 #include "../../../include/pbrs_scene_spec.h"
 #include "dmath.h"
 
+struct pbrs_wnode;  // device/wide.h
 struct DevScene {
     // Every BVH node of the scene in one array with absolute links: the TLAS at 0 (root = node 0), its leaves again at
     // flat_off when the TLAS is small (below), then the BLASes; a mesh instance's blas_root is an index into it.
@@ -50,6 +51,10 @@ struct DevScene {
     // copy of an instance carries its material's class in pad[0].  More than one class with lobes: the bounce queues are
     // ordered by class before k_shade (kernels.h, k_class_sort).
     uint32_t n_classes;
+    // Four-wide nodes over every BLAS (device/wide.h; a mesh instance's wide root is in the device copy of its record, pad[1])
+    // and the entries a lane's stack may hold in the kernels that walk them (beyond that a ray goes to the binary-walk kernels)
+    const pbrs_wnode* wnodes;
+    uint32_t wide_cap;
 };
 
 // Scene features the traversal kernels are specialised on (pbrs_upload_scene derives them from the arrays it checks).
@@ -63,6 +68,7 @@ struct DevScene {
 #define PBRS_FEAT_FLAT_TLAS 4u      // the leaf copies at DevScene::flat_off are built: rays on the division-free box test scan the TLAS leaves
 #define PBRS_FEAT_ALL 7u
 #define PBRS_FEAT_LONG_WALKS 8u     // kernels only (not a property of the walks): several node steps per loop round (kernels.h)
+#define PBRS_FEAT_WIDE 16u          // kernels only: the walks over four-wide nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
 #define PBRS_FLAT_TLAS_MIN 2u
 // Largest TLAS the wave scans instead of walking (tools/tlas_probe.py, C5's scene family at 960x540, ms per 64 spp, walk vs
 // scan): closest hit 4.84 / 4.74 at 20 instances, 5.10 / 5.28 at 24, 5.66 / 6.15 at 30 — the scan only filters there and every

@@ -100,6 +100,19 @@ PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
     return t_low <= t_high;
 }
 
+// The same test with an infinite extent, for a ray on the division-free test, returning t_low = max(lo_el, 0) as well: with a
+// finite extent t the reference's test is t_low <= min(hi_el, t), i.e. this result AND t_low <= t — which is how a closest-hit
+// walk re-evaluates a scanned TLAS leaf at its turn without fetching the box again (ClosestWalkW, FlatScan::run_tlow).
+PD bool slab_rs_tlow(const pbrs_node& n, const RaySpace& R, float& t_low) {
+    float t0x = qdiv(n.min[0] - R.o.x, R.rx), t0y = qdiv(n.min[1] - R.o.y, R.ry), t0z = qdiv(n.min[2] - R.o.z, R.rz);
+    float t1x = qdiv(n.max[0] - R.o.x, R.rx), t1y = qdiv(n.max[1] - R.o.y, R.ry), t1z = qdiv(n.max[2] - R.o.z, R.rz);
+    float lo_el = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+    float hi_el = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+    t_low = __builtin_fmaxf(lo_el, 0.0f);
+    return t_low <= hi_el;
+}
+#include "wide.h"
+
 // `self.transform.inverse().apply(*ray)` (tlas/src/instance.rs:51).  For an instance whose matrices are
 // bit-exactly the identity the Mat4 products return the operand's own bits as long as every component
 // is finite and non-zero (1*x + 0*y + 0*z + 0*w = x exactly), which is what W.fast plus a non-zero
@@ -259,6 +272,51 @@ struct FlatScan {
         return mine;
     }
 };
+
+// FlatScan::run with an infinite extent that also leaves, for every leaf that passed, the exact entry distance t_low in the
+// owner's column of a block-wide LDS table (tl_block[leaf * 256 + thread of the owner]).
+PD uint32_t flat_scan_tlow(const DevScene& S, bool fresh, const RaySpace& R, float* tl_block) {
+    const uint64_t m = __ballot(fresh);
+    if (m == 0) return 0u;
+    const uint32_t lane = threadIdx.x & 63u, wave_base = threadIdx.x & ~63u;
+    const uint32_t H = (S.n_flat + 1u) >> 1;
+    const uint32_t total = (uint32_t)__popcll(m) * H;
+    const uint32_t rank = lane_prefix(m);
+    const uint32_t list = (uint32_t)__builtin_amdgcn_ds_permute((int)((fresh ? rank : 63u) << 2), (int)lane);
+    const uint32_t magic = (65536u + H - 1u) / H;
+    uint32_t mine = 0;
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t p = base + lane;
+        const bool valid = p < total;
+        const uint32_t r = (p * magic) >> 16, h = p - r * H;
+        const uint32_t owner = FlatScan::pull(r, list);
+        RaySpace O;
+        O.o = mk3(FlatScan::pull(owner, R.o.x), FlatScan::pull(owner, R.o.y), FlatScan::pull(owner, R.o.z));
+        O.d = gray(0.0f);
+        O.rx = FlatScan::pull(owner, R.rx);
+        O.ry = FlatScan::pull(owner, R.ry);
+        O.rz = FlatScan::pull(owner, R.rz);
+        O.fast = true;
+        bool pass0 = false, pass1 = false;
+        if (valid) {
+            float t_low;
+            pass0 = slab_rs_tlow(load_node(S.nodes + S.flat_off + h), O, t_low);
+            if (pass0) tl_block[h * PBRS_TRAVERSAL_BLOCK + wave_base + owner] = t_low;
+            if (h + H < S.n_flat) {
+                pass1 = slab_rs_tlow(load_node(S.nodes + S.flat_off + h + H), O, t_low);
+                if (pass1) tl_block[(h + H) * PBRS_TRAVERSAL_BLOCK + wave_base + owner] = t_low;
+            }
+        }
+        const uint64_t w0 = __ballot(pass0), w1 = __ballot(pass1);
+        const int sft = (int)(rank * H) - (int)base;
+        if (fresh && sft > -(int)H && sft < 64) {
+            const uint64_t a = sft >= 0 ? w0 >> sft : w0 << -sft, b = sft >= 0 ? w1 >> sft : w1 << -sft;
+            const uint32_t keep = (1u << H) - 1u;
+            mine |= ((uint32_t)a & keep) | (((uint32_t)b & keep) << H);
+        }
+    }
+    return mine;
+}
 
 template <bool STATS, uint32_t FEAT>
 struct ClosestWalk {
@@ -739,6 +797,346 @@ struct AnyWalk {
     }
 };
 
+// ---- walks over four-wide nodes (device/wide.h) ----------------------------------------------------------------------------
+// For scenes whose TLAS is scanned (PBRS_FEAT_FLAT_TLAS) and rays on the division-free box test.  Same states, same boundary
+// and leaf steps as the binary walks above — they inherit them — but: inside a mesh a node step takes a WIDE node (four boxes
+// through the conservative filter, the survivors pushed in the reference's order, the first one kept in a register); a BLAS leaf
+// that comes up is held UNVERIFIED until the shared leaf step gives it the reference's own box test with the extent of that
+// moment; at the TLAS level a scanned leaf is re-evaluated at its turn from the entry distance the scan left in LDS (t_low <=
+// t_max: the reference's test, slab_rs_tlow) — no box is fetched twice.  A ray that leaves the guarded range (at its start or
+// inside an instance) or whose stack would exceed DevScene::wide_cap takes mode PBRS_WALK_SLOW: the kernel hands it, whole, to
+// the binary-walk kernel (kernels.h).
+#define PBRS_WALK_SLOW 6u
+#define PBRS_LEAF_UNVERIFIED 0xffffffffu
+template <uint32_t FEAT>
+struct ClosestWalkW : ClosestWalk<false, FEAT> {
+    using B = ClosestWalk<false, FEAT>;
+    using B::C; using B::best; using B::t_max; using B::lt; using B::mt; using B::mb1; using B::mb2; using B::mprim; using B::cur_inst;
+    using B::inst_info; using B::leaf_a; using B::leaf_end; using B::sp; using B::blas_base; using B::cand; using B::in_blas; using B::moved; using B::mode;
+    WideRay W;
+    uint32_t cur;  // wide node to take next (the nearest survivor of the last node step), or PBRS_WREF_NONE
+    // A BLAS leaf held UNVERIFIED is (leaf_a = its node index, leaf_end = PBRS_LEAF_UNVERIFIED); the scanned TLAS leaf about to be
+    // entered travels in leaf_a too.  The lane's column of the block's entry-distance table sits after the stack rows:
+    // row DevScene::wide_cap + k for scanned leaf k.  A wide walk is never below a TLAS entry (the TLAS is scanned): blas_base = 0.
+
+    PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
+        B::start(S, o, d, tmax, stk);
+        cur = PBRS_WREF_NONE;
+        W.set(C);
+        if (mode != PBRS_WALK_SCAN) mode = PBRS_WALK_SLOW;  // not on the division-free test: the binary walk's ray
+    }
+    PD void scan_wave(const DevScene& S, LaneStack stk) {
+        float* tl_block = reinterpret_cast<float*>(stk.base) - (threadIdx.x & (PBRS_TRAVERSAL_BLOCK - 1)) + S.wide_cap * PBRS_TRAVERSAL_BLOCK;
+        const uint32_t mine = flat_scan_tlow(S, mode == PBRS_WALK_SCAN, C, tl_block);
+        if (mode == PBRS_WALK_SCAN) {
+            cand = mine;
+            mode = PBRS_WALK_NODE;
+        }
+    }
+    PD uint32_t after_leaf() const { return sp == 0 ? B::exit_mode() : PBRS_WALK_NODE; }
+    PD void hold_leaf(uint32_t ref) {
+        leaf_a = ref & ~PBRS_WREF_LEAF;
+        leaf_end = PBRS_LEAF_UNVERIFIED;
+        mode = PBRS_WALK_LEAF;
+    }
+    // The f64 reciprocals are not state of a wide walk (exact_space): dropping them at the end of every loop round keeps six
+    // registers from living across it (the shared scan reads them from every lane of the wave, fresh or not).
+    PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
+    PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
+        uint32_t e = cur;
+        if (e == PBRS_WREF_NONE) {
+            if (!in_blas) {  // TLAS level: the next scanned leaf whose box the reference's test passes NOW (t_low <= min(hi_el, t_max))
+                if (cand == 0u) {
+                    mode = PBRS_WALK_DONE;
+                    return;
+                }
+                const uint32_t k = (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1u;
+                if (__uint_as_float(stk.get((int)(S.wide_cap + k))) <= t_max) {
+                    leaf_a = k;
+                    mode = PBRS_WALK_XFER;
+                }
+                return;
+            }
+            if (sp == 0) {
+                mode = B::exit_mode();
+                return;
+            }
+            e = stk.get(--sp);
+        }
+        cur = PBRS_WREF_NONE;
+        if (e & PBRS_WREF_LEAF) {
+            hold_leaf(e);
+            return;
+        }
+        const WideTest t = wide_test(S.wnodes, e, C, W, lt);  // inside a mesh lt == mt at every node (blas.rs:468), after the root
+        if (t.pass == 0u) {
+            if (sp == 0) mode = B::exit_mode();
+            return;
+        }
+        if (sp + 3 > (int)S.wide_cap) {  // the pushes below might not fit: the binary walk takes this ray from its start
+            mode = PBRS_WALK_SLOW;
+            return;
+        }
+        const uint32_t first = wide_push(wide_order(t, C.d), stk, sp);  // the reference's order; its first is taken next, from the register
+        if (first & PBRS_WREF_LEAF) hold_leaf(first);
+        else cur = first;
+    }
+    PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
+        if (in_blas) {
+            const bool rebuilt = moved && !(inst_info & 0x40000000u);  // leave_instance rebuilds the world ray, reciprocals included
+            B::xfer_step(S, stk, cnt);  // the way out: Instance::intersect returns (bvh.rs:82-95)
+            if (rebuilt) W.set(C);
+            return;
+        }
+        mode = PBRS_WALK_NODE;
+        const pbrs_node leaf = load_node(S.nodes + S.flat_off + leaf_a);  // its box passed at this moment (node_step)
+        cur_inst = leaf.a;
+        const uint32_t kind = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+        inst_info = kind;
+        const pbrs_instance& in = S.inst[cur_inst];
+        if ((FEAT & PBRS_FEAT_ANALYTIC) && kind != PBRS_SHAPE_MESH && kind != PBRS_SHAPE_TRIANGLE) {
+            B::analytic_visit(S, in, kind, cnt);
+            return;
+        }
+        const uint32_t space = enter_instance(S, in, C, kind == PBRS_SHAPE_MESH, stk);
+        moved = space != PBRS_SPACE_WORLD;
+        in_blas = true;
+        blas_base = 0;
+        lt = t_max;
+        mt = pn_inf();
+        if (kind == PBRS_SHAPE_MESH) {
+            if (!C.fast) {  // the instance's space is outside the guarded range
+                mode = PBRS_WALK_SLOW;
+                return;
+            }
+            inst_info = kind | (in.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
+            if (space == PBRS_SPACE_MOVED) W.set(C);  // a new direction (make_space has just computed its reciprocals); else the world's stands
+            if (in.pad[1] == PBRS_WREF_NONE) {  // the mesh is one leaf: its box is tested, against the incoming extent, with its triangles
+                hold_leaf(in.blas_root);
+                return;
+            }
+            // the root against the incoming extent (blas.rs:441 at the first pop), the reference's test; then lt = mt (:468)
+            if (!slab_rs(load_node(S.nodes + in.blas_root), exact_space(C), lt)) {
+                mode = B::exit_mode();
+                return;
+            }
+            lt = mt;
+            cur = in.pad[1];
+        } else if (kind == PBRS_SHAPE_TRIANGLE) {
+            inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
+            leaf_a = in.blas_root;
+            leaf_end = in.blas_root + 1u;
+            mode = PBRS_WALK_LEAF;
+        }
+    }
+    // The held leaves of the whole wave: first the reference's box test for the unverified ones, then ClosestWalk::leaf_wave's
+    // shared triangle tests (same values, same order).
+    PD void leaf_wave(const DevScene& S, Cnt<false>& cnt) {
+        if (mode == PBRS_WALK_LEAF && leaf_end == PBRS_LEAF_UNVERIFIED) {
+            const pbrs_node node = load_node(S.nodes + leaf_a);
+            leaf_a = node.a;
+            leaf_end = node.a;
+            if (slab_rs(node, exact_space(C), lt)) {
+                leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
+                if (leaf_end == leaf_a) lt = mt;  // an empty leaf still runs blas.rs:468
+            }
+            if (leaf_end == leaf_a) mode = after_leaf();
+        }
+        const bool tri_leaf = mode == PBRS_WALK_LEAF;
+        TriShare sh;
+        sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
+        if (sh.has[0] == 0) return;
+        const f3 ho = sh.from_owner(C.o), hd = sh.from_owner(C.d);
+        const float hlt = sh.from_owner(lt);
+        const uint32_t hti = sh.from_owner(leaf_a) + sh.k();
+        const uint32_t hinfo = (FEAT & PBRS_FEAT_SHADING_CHECK) ? sh.from_owner(inst_info) : 0u;
+        const float hmt = (FEAT & PBRS_FEAT_SHADING_CHECK) ? sh.from_owner(mt) : 0.0f;
+        float rt = pn_inf(), rb1 = 0.0f, rb2 = 0.0f;
+        if (sh.helper()) {
+            pbrs_tri_verts tv = load_tri(S.tv + hti);
+            TriHit h;
+            constexpr bool need_bary = (FEAT & PBRS_FEAT_SHADING_CHECK) != 0u;
+            bool hit = mesh_tri_hit_t<need_bary>(tv, ho, hd, hlt, S.fast_slab != 0u, h);
+            if ((FEAT & PBRS_FEAT_SHADING_CHECK) && hit && h.t < hmt && !((hinfo >> 3) & PBRS_MESH_SHADING_OK_MASK)) {
+                f3 n, dpdu;
+                hit = mesh_tri_shading(tv, S.ts[hti], hd, h, n, dpdu);
+            }
+            if (hit) {
+                rt = h.t;
+                rb1 = h.b1;
+                rb2 = h.b2;
+            }
+        }
+        uint32_t win = 0xffffffffu, win_tri = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (sh.has[j] == 0) break;
+            const uint32_t at = sh.pos(j);
+            const float t = sh.from_helper(at, rt);
+            if (j < sh.cnt && t < mt) {
+                mt = t;
+                win = at;
+                win_tri = leaf_a + j;
+            }
+        }
+        if (__ballot(win != 0xffffffffu)) {
+            const float b1 = sh.from_helper(win, rb1), b2 = sh.from_helper(win, rb2);
+            if (win != 0xffffffffu) {
+                mprim = (inst_info & 7u) == PBRS_SHAPE_MESH ? win_tri : 0u;
+                mb1 = b1;
+                mb2 = b2;
+            }
+        }
+        if (tri_leaf) {
+            leaf_a += sh.cnt;
+            if (leaf_a == leaf_end) {
+                mode = after_leaf();
+                lt = mt;
+            }
+        }
+    }
+};
+
+template <uint32_t FEAT>
+struct AnyWalkW : AnyWalk<false, FEAT> {
+    using B = AnyWalk<false, FEAT>;
+    using B::C; using B::t_max; using B::leaf_a; using B::leaf_end; using B::inst_kind; using B::sp; using B::blas_base; using B::cand; using B::in_blas;
+    using B::occluded; using B::moved; using B::mode;
+    WideRay W;
+    uint32_t cur;
+
+    PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
+        B::start(S, o, d, tmax, stk);
+        cur = PBRS_WREF_NONE;
+        W.set(C);
+        if (mode != PBRS_WALK_SCAN) mode = PBRS_WALK_SLOW;
+    }
+    PD void scan_wave(const DevScene& S, LaneStack) {
+        Cnt<false> cnt;
+        B::scan_wave(S, cnt);
+    }
+    PD uint32_t after_leaf() const { return sp == 0 ? B::exit_mode() : PBRS_WALK_NODE; }
+    PD void hold_leaf(uint32_t ref) {
+        leaf_a = ref & ~PBRS_WREF_LEAF;
+        leaf_end = PBRS_LEAF_UNVERIFIED;
+        mode = PBRS_WALK_LEAF;
+    }
+    PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
+    PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
+        uint32_t e = cur;
+        if (e == PBRS_WREF_NONE) {
+            if (!in_blas) {  // TLAS level: the next leaf that passed the scan (the reference's test: the extent never changes)
+                if (cand == 0u) {
+                    mode = PBRS_WALK_DONE;
+                    return;
+                }
+                leaf_a = (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1u;
+                mode = PBRS_WALK_XFER;
+                return;
+            }
+            if (sp == 0) {
+                mode = B::exit_mode();
+                return;
+            }
+            e = stk.get(--sp);
+        }
+        cur = PBRS_WREF_NONE;
+        if (e & PBRS_WREF_LEAF) {
+            hold_leaf(e);
+            return;
+        }
+        const WideTest t = wide_test(S.wnodes, e, C, W, t_max);
+        if (t.pass == 0u) {
+            if (sp == 0) mode = B::exit_mode();
+            return;
+        }
+        if (sp + 3 > (int)S.wide_cap) {
+            mode = PBRS_WALK_SLOW;
+            return;
+        }
+        const uint32_t first = wide_push(wide_order_any(t, C.d), stk, sp);
+        if (first & PBRS_WREF_LEAF) hold_leaf(first);
+        else cur = first;
+    }
+    PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
+        if (in_blas) {
+            const bool rebuilt = moved && !(inst_kind & 0x100u);
+            B::xfer_step(S, stk, cnt);
+            if (rebuilt) W.set(C);
+            return;
+        }
+        mode = PBRS_WALK_NODE;
+        const pbrs_node leaf = load_node(S.nodes + S.flat_off + leaf_a);
+        leaf_a = leaf.a;  // the instance
+        inst_kind = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+        const pbrs_instance& in = S.inst[leaf_a];
+        if ((FEAT & PBRS_FEAT_ANALYTIC) && inst_kind != PBRS_SHAPE_MESH && inst_kind != PBRS_SHAPE_TRIANGLE) {
+            B::analytic_visit(S, in, cnt);
+            return;
+        }
+        const uint32_t space = enter_instance(S, in, C, inst_kind == PBRS_SHAPE_MESH, stk);
+        moved = space != PBRS_SPACE_WORLD;
+        in_blas = true;
+        blas_base = 0;
+        if (inst_kind == PBRS_SHAPE_MESH) {
+            if (!C.fast) {
+                mode = PBRS_WALK_SLOW;
+                return;
+            }
+            if (space == PBRS_SPACE_TRANSLATED) inst_kind |= 0x100u;
+            if (space == PBRS_SPACE_MOVED) W.set(C);
+            if (in.pad[1] == PBRS_WREF_NONE) {
+                hold_leaf(in.blas_root);
+                return;
+            }
+            if (!slab_rs(load_node(S.nodes + in.blas_root), exact_space(C), t_max)) {  // the root's own test is not needed for the answer, but it is one test that ends most misses here
+                mode = B::exit_mode();
+                return;
+            }
+            cur = in.pad[1];
+        } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {
+            leaf_a = in.blas_root;
+            leaf_end = in.blas_root + 1u;
+            mode = PBRS_WALK_LEAF;
+        }
+    }
+    PD void leaf_wave(const DevScene& S, Cnt<false>& cnt) {
+        if (mode == PBRS_WALK_LEAF && leaf_end == PBRS_LEAF_UNVERIFIED) {  // the reference's test of the leaf's own box (intersect_bvh_pred, blas.rs:478-495)
+            const pbrs_node node = load_node(S.nodes + leaf_a);
+            leaf_a = node.a;
+            leaf_end = slab_rs(node, exact_space(C), t_max) ? node.a + (node.b & ~PBRS_LEAF_FLAG) : node.a;
+            if (leaf_end == leaf_a) mode = after_leaf();
+        }
+        const bool tri_leaf = mode == PBRS_WALK_LEAF;
+        TriShare sh;
+        sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
+        if (sh.has[0] == 0) return;
+        const f3 ho = sh.from_owner(C.o), hd = sh.from_owner(C.d);
+        const float htmax = sh.from_owner(t_max);
+        const uint32_t hti = sh.from_owner(leaf_a) + sh.k();
+        bool hit = false;
+        if (sh.helper()) {
+            pbrs_tri_verts tv = load_tri(S.tv + hti);
+            hit = mesh_tri_pred(tv, ho, hd, htmax);
+        }
+        const uint64_t hits = __ballot(hit);
+        if (tri_leaf) {
+            bool occ = false;
+#pragma unroll
+            for (uint32_t j = 4u; j-- > 0u;)
+                if (j < sh.cnt && ((hits >> sh.pos(j)) & 1ull)) occ = true;
+            leaf_a += sh.cnt;
+            mode = leaf_a != leaf_end ? PBRS_WALK_LEAF : after_leaf();
+            if (occ) {
+                occluded = true;
+                mode = PBRS_WALK_DONE;
+            }
+        }
+    }
+};
+
 // One ray per lane start to finish (parity harness; the pipeline kernels interleave walks and refill lanes instead).
 // Every lane of the wave calls these together (leaf_wave); `active` = the lane has a ray.
 template <bool STATS>
@@ -767,4 +1165,45 @@ PD bool tlas_any(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneSt
         if (__ballot(w.mode == PBRS_WALK_LEAF)) w.leaf_wave(S, cnt);
     }
     return w.occluded;
+}
+// The same through the wide walks (parity harness of the kernels that walk four-wide nodes): rays those walks refuse fall back
+// to the binary walk, as they do in the pipeline.  The block's entry-distance table sits after DevScene::wide_cap stack rows.
+PD void tlas_closest_wide(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneStack stk, Hit& best) {
+    Cnt<false> cnt;
+    ClosestWalkW<PBRS_FEAT_ALL> w;
+    w.start(S, o, d, t_max, stk);
+    if (!active) w.mode = PBRS_WALK_DONE;
+    w.scan_wave(S, stk);
+    while (__ballot(w.mode == PBRS_WALK_NODE || w.mode == PBRS_WALK_LEAF || w.mode == PBRS_WALK_XFER)) {
+        if (w.mode == PBRS_WALK_XFER) w.xfer_step(S, stk, cnt);
+        if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
+        if (__ballot(w.mode == PBRS_WALK_LEAF)) w.leaf_wave(S, cnt);
+    }
+    const bool slow = w.mode == PBRS_WALK_SLOW;
+    w.finish(cnt);
+    best = w.best;
+    if (__ballot(slow)) {
+        Hit b2;
+        tlas_closest<false>(S, active && slow, o, d, t_max, stk, b2, cnt);
+        if (slow) best = b2;
+    }
+}
+PD bool tlas_any_wide(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneStack stk) {
+    Cnt<false> cnt;
+    AnyWalkW<PBRS_FEAT_ALL> w;
+    w.start(S, o, d, t_max, stk);
+    if (!active) w.mode = PBRS_WALK_DONE;
+    w.scan_wave(S, stk);
+    while (__ballot(w.mode == PBRS_WALK_NODE || w.mode == PBRS_WALK_LEAF || w.mode == PBRS_WALK_XFER)) {
+        if (w.mode == PBRS_WALK_XFER) w.xfer_step(S, stk, cnt);
+        if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
+        if (__ballot(w.mode == PBRS_WALK_LEAF)) w.leaf_wave(S, cnt);
+    }
+    const bool slow = w.mode == PBRS_WALK_SLOW;
+    bool occ = w.occluded;
+    if (__ballot(slow)) {
+        const bool o2 = tlas_any<false>(S, active && slow, o, d, t_max, stk, cnt);
+        if (slow) occ = o2;
+    }
+    return occ;
 }

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -24,7 +25,10 @@ namespace {
 constexpr uint32_t kBlock = 256;
 constexpr uint32_t kMaxDepth = 64;
 constexpr uint32_t kHeadWords = PBRS_WORK_HEADS * PBRS_WORK_HEAD_STRIDE;
-constexpr uint32_t kCounterWords = (3 + 2 * kHeadWords) * (kMaxDepth + 2);  // act, ns (u64), then the work heads
+// per bounce: act, ns (u64), the slow-list lengths of k_extend and k_shadow; then four sets of work heads (the two stages, and
+// the binary-walk launches that work off their slow lists)
+constexpr uint32_t kCounterWords = (5 + 4 * kHeadWords) * (kMaxDepth + 2);
+constexpr uint32_t kSlowGrid = 64;  // blocks of a binary-walk launch over a slow list (empty in nearly every launch)
 constexpr uint32_t kStreamGridCap = 4096;  // blocks of k_nee_resolve, whose work is counted on the device (kernels.h)
 constexpr uint32_t kPersistentBlocks = PBRS_PERSISTENT_BLOCKS;  // 256 CUs x up to 6 resident 256-thread blocks (VGPR/LDS permitting)
 constexpr size_t kLdsBytesPerCU = 160 * 1024;
@@ -85,6 +89,8 @@ struct pbrs_ctx {
     uint32_t shade_spec = 0;       // PBRS_SHADE_*: what k_shade<PATH> may leave out for this scene
     bool long_walks = false;       // a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: the PBRS_FEAT_LONG_WALKS kernels
     bool shadow_flat = false;      // k_shadow scans the TLAS leaves (up to PBRS_FLAT_TLAS_MAX_ANYHIT instances; k_extend: S.features)
+    bool wide_extend = false, wide_shadow = false;  // the stage runs the walks over four-wide nodes (device/wide.h), the binary walks after it for what they refuse
+    uint32_t* slow = nullptr;      // 2 * cap_slots: queue positions a wide-walk kernel handed to the binary-walk kernel
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
     bool sort_classes = true;      // PBRS_SORT_CLASSES=0 in the environment turns the class sort off (A/B timing)
     uint64_t pending_closest = 0;
@@ -134,6 +140,7 @@ void free_work(pbrs_ctx* c) {
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
     c->state_mem = nullptr;
     c->neeq = nullptr;
+    c->slow = nullptr;
     c->sum = nullptr;
     c->rgb_dev = nullptr;
 }
@@ -146,6 +153,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         c->cap_slots = 0;
         c->st = PathState{};
         c->neeq = nullptr;
+        c->slow = nullptr;
         if (c->state_mem) (void)hipFree(c->state_mem);
         c->state_mem = nullptr;
         auto align = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -153,7 +161,8 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         // q[2][3], hit, L, nee[3]: one float4 per path each; sr[3]: two per path; occ: two bytes; nee queue: one word
         const size_t n_tiles = n_slots / PBRS_SORT_TILE + 1;
         const size_t sort_bytes = align(n_tiles * PBRS_MAX_CLASSES * sizeof(uint32_t)) + align((PBRS_MAX_CLASSES + 1) * sizeof(uint2));
-        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + 2 * align(n_slots * sizeof(uint32_t)) + sort_bytes + align(n_slots);
+        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + 2 * align(n_slots * sizeof(uint32_t)) + sort_bytes + align(n_slots) +
+                             align(2 * n_slots * sizeof(uint32_t));
         hipError_t e = hipMalloc(&c->state_mem, total);
         if (e != hipSuccess) {
             c->state_mem = nullptr;
@@ -175,6 +184,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         c->neeq = reinterpret_cast<uint32_t*>(take(align(n_slots * sizeof(uint32_t))));
         s.perm = reinterpret_cast<uint32_t*>(take(align(n_slots * sizeof(uint32_t))));
         s.cls = reinterpret_cast<uint8_t*>(take(align(n_slots)));
+        c->slow = reinterpret_cast<uint32_t*>(take(align(2 * n_slots * sizeof(uint32_t))));
         s.tile_hist = reinterpret_cast<uint32_t*>(take(align(n_tiles * PBRS_MAX_CLASSES * sizeof(uint32_t))));
         s.class_range = reinterpret_cast<uint2*>(take(align((PBRS_MAX_CLASSES + 1) * sizeof(uint2))));
         c->st = s;
@@ -193,6 +203,10 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
     return PBRS_OK;
 }
 
+// wide-walk kernels: DevScene::wide_cap stack rows, and for closest hit one row per scanned TLAS leaf (entry distances)
+size_t lds_bytes_wide(const pbrs_ctx* c, bool closest) {
+    return (size_t)(c->S.wide_cap + (closest ? c->S.n_flat : 0u)) * kBlock * sizeof(uint32_t);
+}
 size_t lds_bytes(const pbrs_ctx* c) {
     size_t b = (size_t)(c->stack_depth) * kBlock * sizeof(uint32_t);
     if (const char* e = dev_env("PBRS_LDS_MIN")) b = b < (size_t)atol(e) ? (size_t)atol(e) : b;  // lowers the occupancy of the traversal kernels
@@ -224,6 +238,44 @@ int check_params(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* 
     // records keep two flag bits next to the slot index, and 16-byte records are addressed with 32-bit element indices
     if ((uint64_t)p->w * p->h * auto_samples_per_pass(c, p) >= (1ull << 28)) return fail(c, PBRS_E_LIMIT, "tile x samples_per_pass above 2^28 paths");
     return PBRS_OK;
+}
+
+// Four-wide nodes over the binary subtree of inner node x (device/wide.h): the boxes of x's grandchildren — or of a child that is
+// a leaf — in left-first order, with the three split axes that order them.  Returns the index of x's wide node in `out`.
+// `nodes`: DevScene::nodes as uploaded (absolute links; checked: children come after their parent, so the recursion ends).
+uint32_t build_wide(const std::vector<pbrs_node>& nodes, uint32_t x, std::vector<pbrs_wnode>& out, uint32_t level, uint32_t& levels) {
+    const uint32_t me = (uint32_t)out.size();
+    out.push_back(pbrs_wnode{});
+    levels = std::max(levels, level + 1u);
+    uint32_t slot_node[4] = {0, 0, 0, 0};
+    uint32_t used = 0, info = nodes[x].b & 3u;
+    const uint32_t child[2] = {x + 1u, nodes[x].a};
+    for (uint32_t s = 0; s < 2; ++s) {
+        const pbrs_node& ch = nodes[child[s]];
+        if (ch.b & PBRS_LEAF_FLAG) {
+            slot_node[2 * s] = child[s];
+            used |= 1u << (2 * s);
+        } else {
+            info |= (ch.b & 3u) << (2 + 2 * s);
+            slot_node[2 * s] = child[s] + 1u;
+            slot_node[2 * s + 1] = ch.a;
+            used |= 3u << (2 * s);
+        }
+    }
+    pbrs_wnode w{};
+    for (uint32_t k = 0; k < 4; ++k) {
+        w.child[k] = PBRS_WREF_NONE;
+        if (!((used >> k) & 1u)) continue;
+        const pbrs_node& n = nodes[slot_node[k]];
+        for (int a = 0; a < 3; ++a) {
+            w.lo[a][k] = n.min[a];
+            w.hi[a][k] = n.max[a];
+        }
+        w.child[k] = (n.b & PBRS_LEAF_FLAG) ? (PBRS_WREF_LEAF | slot_node[k]) : build_wide(nodes, slot_node[k], out, level + 1u, levels);
+    }
+    w.info = info | used << 8;
+    out[me] = w;
+    return me;
 }
 
 struct Timer {
@@ -303,18 +355,40 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
 
 // The traversal kernels are instantiated per scene-feature set (device/shapes.h PBRS_FEAT_*); the instrumented variant
 // exists for the full set only.  k_shadow never evaluates shading frames, so only PBRS_FEAT_ANALYTIC selects it.
-void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* heads) {
+// `wide`: the walks over four-wide nodes (scenes with a scanned TLAS); `indirect` / `slow_*`: see kernels.h.
+void launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* heads,
+                   const uint32_t* indirect, uint32_t* slow_list, uint32_t* slow_count) {
     // k_extend scans the TLAS leaves only up to PBRS_FLAT_TLAS_MAX instances (S.features); the leaf copies may exist for
     // k_shadow alone, and the instrumented variant, which carries every feature, must then walk the tree like the timed one
     DevScene S = c->S;
     if (!(S.features & PBRS_FEAT_FLAT_TLAS)) S.n_flat = 0u;
 #define PBRS_LAUNCH_EXTEND(ST, F) \
-    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt)
+    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt, indirect, slow_list, slow_count)
     if (stats) {
         PBRS_LAUNCH_EXTEND(true, PBRS_FEAT_ALL);
         return;
     }
-    switch ((c->S.features & PBRS_FEAT_ALL) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
+    const uint32_t feat = (c->S.features & PBRS_FEAT_ALL) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u);
+#ifdef PBRS_DEV_OVERRIDES  // the wide closest-hit walk is slower than the binary one (pbrs_upload_scene): developer builds only
+    if (wide) {  // PBRS_FEAT_FLAT_TLAS is set (pbrs_upload_scene)
+#define W PBRS_FEAT_WIDE | PBRS_FEAT_FLAT_TLAS
+        switch (feat & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_LONG_WALKS)) {
+            case 0u: PBRS_LAUNCH_EXTEND(false, W); break;
+            case 1u: PBRS_LAUNCH_EXTEND(false, W | 1u); break;
+            case 2u: PBRS_LAUNCH_EXTEND(false, W | 2u); break;
+            case 3u: PBRS_LAUNCH_EXTEND(false, W | 3u); break;
+            case 8u: PBRS_LAUNCH_EXTEND(false, W | 8u); break;
+            case 9u: PBRS_LAUNCH_EXTEND(false, W | 9u); break;
+            case 10u: PBRS_LAUNCH_EXTEND(false, W | 10u); break;
+            default: PBRS_LAUNCH_EXTEND(false, W | 11u); break;
+        }
+#undef W
+        return;
+    }
+#else
+    (void)wide;
+#endif
+    switch (feat) {
         case 0u: PBRS_LAUNCH_EXTEND(false, 0u); break;
         case 1u: PBRS_LAUNCH_EXTEND(false, 1u); break;
         case 2u: PBRS_LAUNCH_EXTEND(false, 2u); break;
@@ -334,12 +408,24 @@ void launch_extend(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, uint32_t 
     }
 #undef PBRS_LAUNCH_EXTEND
 }
-void launch_shadow(pbrs_ctx* c, bool stats, uint32_t grid, size_t lds, const uint32_t* count, uint32_t* heads) {
+void launch_shadow(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds, const uint32_t* count, uint32_t* heads, const uint32_t* indirect,
+                   uint32_t* slow_list, uint32_t* slow_count) {
 #define PBRS_LAUNCH_SHADOW(ST, F) \
-    hipLaunchKernelGGL((k_shadow<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, count, heads, c->gcnt + 1)
+    hipLaunchKernelGGL((k_shadow<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, count, heads, c->gcnt + 1, indirect, slow_list, slow_count)
     // k_shadow never evaluates shading frames: PBRS_FEAT_SHADING_CHECK does not select it
     if (stats) {
         PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS);
+        return;
+    }
+    if (wide) {
+#define W PBRS_FEAT_WIDE | PBRS_FEAT_FLAT_TLAS
+        switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
+            case 0u: PBRS_LAUNCH_SHADOW(false, W); break;
+            case 1u: PBRS_LAUNCH_SHADOW(false, W | 1u); break;
+            case 8u: PBRS_LAUNCH_SHADOW(false, W | 8u); break;
+            default: PBRS_LAUNCH_SHADOW(false, W | 9u); break;
+        }
+#undef W
         return;
     }
     switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->shadow_flat ? PBRS_FEAT_FLAT_TLAS : 0u) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
@@ -370,8 +456,14 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     // ns[b]: one 64-bit word per bounce: low half = paths whose light estimate waits for visibility, high half = shadow rays
     unsigned long long* ns = reinterpret_cast<unsigned long long*>(c->counters + stride);
     // work-fetch heads of k_extend / k_shadow: kHeadWords words per bounce (one head per queue segment, kernels.h)
-    uint32_t* xhead = c->counters + 3 * stride;
+    uint32_t* slowx = c->counters + 3 * stride;  // slow-list lengths per bounce: k_extend's, k_shadow's
+    uint32_t* slows = slowx + stride;
+    uint32_t* xhead = c->counters + 5 * stride;
     uint32_t* shead = xhead + stride * kHeadWords;
+    uint32_t* xhead2 = shead + stride * kHeadWords;  // the binary-walk launches over the slow lists
+    uint32_t* shead2 = xhead2 + stride * kHeadWords;
+    const bool wide_x = c->wide_extend && !stats, wide_s = c->wide_shadow && !stats;
+    const size_t lds_wx = lds_bytes_wide(c, true), lds_ws = lds_bytes_wide(c, false);
     uint32_t* neeq = c->neeq;
     HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(uint32_t), c->stream));
     if (tm.begin(0)) return fail(c, PBRS_E_DEVICE, "event record failed");
@@ -387,7 +479,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         // queue length of bounce 0 is the pass size, later ones are counted on the device
         const uint32_t* cnt_in = b == 0 ? nullptr : act + b;
         if (tm.begin(1)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        launch_extend(c, stats, pgrid, lds, b & 1u, cnt_in, N, xhead + b * kHeadWords);
+        launch_extend(c, stats, wide_x, pgrid, wide_x ? lds_wx : lds, b & 1u, cnt_in, N, xhead + b * kHeadWords, nullptr, c->slow, slowx + b);
+        if (wide_x)  // what the wide walks refused (rays outside the guarded range of the division-free box test, overlong stacks)
+            launch_extend(c, false, false, pgrid < kSlowGrid ? pgrid : kSlowGrid, lds, b & 1u, slowx + b, 0u, xhead2 + b * kHeadWords, c->slow, nullptr, nullptr);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
         // several shading classes (and an integrator that shades): order the queue by class first; counted as shade time
@@ -446,7 +540,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         }
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        launch_shadow(c, stats, pgrid, lds, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords);
+        launch_shadow(c, stats, wide_s, pgrid, wide_s ? lds_ws : lds, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords, nullptr, c->slow, slows + b);
+        if (wide_s)
+            launch_shadow(c, false, false, pgrid < kSlowGrid ? pgrid : kSlowGrid, lds, slows + b, shead2 + b * kHeadWords, c->slow, nullptr, nullptr);
         hipLaunchKernelGGL(k_nee_resolve, dim3(sgrid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
         tm.end();
     }
@@ -556,7 +652,12 @@ int configure_kernels(pbrs_ctx* c) {
         PBRS_K((k_extend<true, PBRS_FEAT_ALL>)),
         PBRS_K((k_shadow<false, 0u>)), PBRS_K((k_shadow<false, 1u>)), PBRS_K((k_shadow<false, 4u>)), PBRS_K((k_shadow<false, 5u>)),
         PBRS_K((k_shadow<false, 8u>)), PBRS_K((k_shadow<false, 9u>)), PBRS_K((k_shadow<false, 12u>)), PBRS_K((k_shadow<false, 13u>)),
-        PBRS_K((k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>)), PBRS_K(k_intersect_rays)};
+        PBRS_K((k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>)), PBRS_K(k_intersect_rays<false>), PBRS_K(k_intersect_rays<true>),
+#ifdef PBRS_DEV_OVERRIDES
+        PBRS_K((k_extend<false, 20u>)), PBRS_K((k_extend<false, 21u>)), PBRS_K((k_extend<false, 22u>)), PBRS_K((k_extend<false, 23u>)),
+        PBRS_K((k_extend<false, 28u>)), PBRS_K((k_extend<false, 29u>)), PBRS_K((k_extend<false, 30u>)), PBRS_K((k_extend<false, 31u>)),
+#endif
+        PBRS_K((k_shadow<false, 20u>)), PBRS_K((k_shadow<false, 21u>)), PBRS_K((k_shadow<false, 28u>)), PBRS_K((k_shadow<false, 29u>))};
 #undef PBRS_K
     for (const void* k : traversal_kernels) HIPCHK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     if (c->device < 64) g_kernel_cfg_done[c->device] = true;
@@ -760,6 +861,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     free_scene(c);
     DevScene S{};
     int rc;
+    uint32_t wide_levels = 0;  // wide nodes on the longest way down a BLAS
     {
         // DevScene::nodes: the TLAS, then its leaves alone in pre-order when the TLAS is small (the shared scan), then every
         // BLAS, in one array with absolute links — a walk reads nodes + index whatever tree it is in.
@@ -814,6 +916,28 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             in.flags &= ~PBRS_INSTANCE_TRANSLATION;
             if (linear_identity) in.flags |= PBRS_INSTANCE_TRANSLATION;
         }
+        // Four-wide nodes over every BLAS a mesh instance enters (device/wide.h): pad[1] of the device copy of the instance is
+        // the wide node of its root, PBRS_WREF_NONE where the mesh is a single leaf.
+        {
+            std::vector<pbrs_wnode> wide;
+            std::map<uint32_t, uint32_t> wide_of_root;
+            uint32_t levels = 0;
+            for (pbrs_instance& in : inst) {
+                in.pad[1] = PBRS_WREF_NONE;
+                if (in.shape_kind != PBRS_SHAPE_MESH || (nodes[in.blas_root].b & PBRS_LEAF_FLAG)) continue;
+                auto it = wide_of_root.find(in.blas_root);
+                if (it == wide_of_root.end()) it = wide_of_root.emplace(in.blas_root, build_wide(nodes, in.blas_root, wide, 0u, levels)).first;
+                in.pad[1] = it->second;
+            }
+            if (wide.size() >= 0x7fffffffull) return fail(c, PBRS_E_LIMIT, "too many BVH nodes");
+            const pbrs_wnode* dev = nullptr;
+            if ((rc = upload(c, wide.data(), wide.size(), &dev))) return rc;
+            S.wnodes = dev;
+            // a node step pushes up to three survivors per level; deeper stacks than PBRS_WIDE_STACK_MAX entries are not given LDS:
+            // a ray that would need one (none on the BASELINE scenes) is traced by the binary-walk kernel instead
+            S.wide_cap = std::max(4u, std::min(3u * levels + 1u, (uint32_t)PBRS_WIDE_STACK_MAX));
+            wide_levels = levels;
+        }
         if ((rc = upload(c, inst.data(), inst.size(), &S.inst))) return rc;
     }
     if ((rc = upload(c, d->shapes, d->n_shapes, &S.shapes))) return rc;
@@ -859,6 +983,21 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     c->shadow_flat = S.n_flat != 0u;
     const uint32_t flat_feature = (S.n_flat != 0u && d->n_instances <= PBRS_FLAT_TLAS_MAX) ? PBRS_FEAT_FLAT_TLAS : 0u;
     S.features = flat_feature;
+    // the walks over four-wide nodes: scenes whose TLAS the stage scans and whose coordinates admit the division-free box test
+    // ... and that have a BLAS deep enough for it to matter (PBRS_WIDE_MIN_LEVELS wide nodes on the way down: meshes of a few
+    // triangles are a leaf or two, where the binary walks at their six waves per SIMD are faster — C2: 105 against 140 ms)
+    // k_shadow gains (C4: 250 -> 236 ms per frame at five waves per SIMD); k_extend, whose wide walk needs 117 registers (four
+    // waves per SIMD, or 72 bytes of spills at five), loses against the binary walk at six (459 -> 506 ms) and keeps the binary
+    // walk: its wide kernels exist in developer builds only (PBRS_WIDE bit 0).
+    const bool wide_ok = S.fast_slab != 0u && wide_levels >= PBRS_WIDE_MIN_LEVELS;
+    c->wide_extend = false;
+    c->wide_shadow = c->shadow_flat && wide_ok;
+#ifdef PBRS_DEV_OVERRIDES
+    if (const char* e = dev_env("PBRS_WIDE")) {  // developer override (A/B timing): bit 0 k_extend, bit 1 k_shadow
+        c->wide_extend = flat_feature != 0u && wide_ok && (std::atoi(e) & 1);
+        c->wide_shadow = c->wide_shadow && (std::atoi(e) & 2);
+    }
+#endif
     for (uint32_t i = 0; i < d->n_instances; ++i) {
         const pbrs_instance& in = d->instances[i];
         if (in.shape_kind == PBRS_SHAPE_MESH) {
@@ -970,7 +1109,15 @@ int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const flo
     TRY(hipMemcpyAsync(d_o, h_o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     TRY(hipMemcpyAsync(d_d, h_d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     TRY(hipMemcpyAsync(d_t, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_intersect_rays, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, kPersistentBlocks)), dim3(kBlock), lds_bytes(c), c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ);
+    {
+        // the walks the pipeline runs for this scene: over four-wide nodes where the TLAS is scanned (the binary walks take what
+        // those refuse, as in the pipeline), else the binary walks
+        const uint32_t rows = std::max(c->stack_depth, c->S.wide_cap);
+        const size_t lds = (size_t)(rows + c->S.n_flat) * kBlock * sizeof(uint32_t);
+        const dim3 grid(std::min<uint32_t>((n + kBlock - 1) / kBlock, kPersistentBlocks));
+        if (c->wide_extend && c->wide_shadow) hipLaunchKernelGGL(k_intersect_rays<true>, grid, dim3(kBlock), lds, c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ, rows);
+        else hipLaunchKernelGGL(k_intersect_rays<false>, grid, dim3(kBlock), lds, c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ, rows);
+    }
     TRY(hipGetLastError());
     if (hits_out) TRY(hipMemcpyAsync(hits_out, d_h, (size_t)n * sizeof(pbrs_hit_record), hipMemcpyDeviceToHost, c->stream));
     if (occluded_out) TRY(hipMemcpyAsync(occluded_out, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));

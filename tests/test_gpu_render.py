@@ -588,3 +588,41 @@ def test_c4_at_512_spp_in_chunk_ordered_passes(gpu_ctx):
     ref, ost = OracleScene(sb).render(c["strata_x"], c["strata_y"], c["depth"], 1, tile=tile)
     assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]
     assert (bits(img) == bits(ref)).all()
+
+
+# ---- the walks over four-wide nodes (device/wide.h) and the rays they refuse --------------------------------------------------
+
+def test_wide_walk_kernels_and_their_slow_list_match_oracle(gpu_ctx):
+    """A terrain mesh deep enough for k_shadow's wide walk (32 768 triangles, a scanned TLAS), lit by the scene's sphere lights
+    AND by a distant light that shines straight down: `target.pos - world_radius * 2 * casting_dir - target.pos` is exactly zero
+    in x and z (light/src/lib.rs:77-81), so every shadow ray towards it is outside the guarded range of the division-free box
+    test — the wide-walk kernel hands those to the binary-walk kernel through its slow list, the others it traces itself.  Image,
+    ray counts and invalid samples equal the oracle's; so do hit records and occlusion of synthetic rays with zero components."""
+    sb, c = scenes.build_config("c4", width=192, height=96, nx=128, nz=128)
+    sb.distant_light((0.0, -1.0, 0.0), (1.5, 1.4, 1.3), 700.0)
+    hs = pbrs_amd.HostScene(sb)
+    assert hs.desc.n_triangles == 2 * 128 * 128 + 2
+    gpu_ctx.upload(hs)
+    osc = OracleScene(sb)
+    ref, ost = osc.render(3, 3, c["depth"], 9)
+    img, st = gpu_ctx.render(3, 3, c["depth"], 9)                    # the timed kernels: wide k_shadow + slow list
+    cnt, stc = gpu_ctx.render(3, 3, c["depth"], 9, counters=True)    # the instrumented kernels: binary walks
+    assert ost["tlas_ties"] == 0 and np.isfinite(ref).all()  # (the delta-light estimate has assert sites of its own: panics are not asserted 0)
+    assert (bits(img) == bits(ref)).all()
+    assert (bits(cnt) == bits(ref)).all()
+    assert stc["closest_rays"] == ost["closest_rays"] and stc["shadow_rays"] == ost["shadow_rays"]
+    assert st["invalid_samples"] == ost["nonfinite_samples"]
+    # rays through the parity harness (the wide walks where the pipeline uses them): axis-parallel directions among random ones
+    rng = np.random.default_rng(4)
+    n = 4096
+    o = np.stack([rng.uniform(-90, 90, n), rng.uniform(20, 80, n), rng.uniform(20, 380, n)], axis=1).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[::7, 0] = 0.0
+    d[::11, 2] = 0.0
+    d[::5] = (0.0, -1.0, 0.0)
+    tmax = np.where(rng.uniform(size=n) < 0.5, np.inf, rng.uniform(10, 300, n)).astype(np.float32)
+    gh, gocc = gpu_ctx.intersect(o, d, tmax)
+    oh, oocc, _ = osc.intersect(o, d, tmax)
+    assert (gocc == oocc).all()
+    assert (gh["inst"] == oh["inst"]).all() and (bits(gh["t"]) == bits(oh["t"])).all() and (gh["prim"] == oh["prim"]).all()
+    assert (gh["inst"] != 0xffffffff).mean() > 0.3
