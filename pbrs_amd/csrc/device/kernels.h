@@ -387,7 +387,7 @@ struct AnySel<false, STATS, FEAT> {
 template <bool STATS, uint32_t FEAT>
 __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_EXTEND_WAVES : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES)
     k_extend(DevScene S, PathState st, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect,
-             uint32_t* slow_list, uint32_t* slow_count) {
+             uint32_t* slow_list, uint32_t* slow_count, uint32_t split) {
     extern __shared__ uint32_t lds_stack[];
     constexpr bool WIDE = !STATS && (FEAT & PBRS_FEAT_WIDE) != 0u;
     const uint32_t n = count ? *count : n_direct;
@@ -415,18 +415,33 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                 // k_shade rebuilds the Interaction from (t, inst, prim): the barycentrics are recomputed there, as the
                 // reference's intersect does for the winning primitive
                 // the 4th word names the hit's shading class (pbrs_upload_scene: DevScene::inst_class), 0 for a miss
-                const uint32_t cls = (S.n_classes > 1u && h.inst != 0xffffffffu) ? S.inst[h.inst].pad[0] : 0u;
-                st.hit[item] = make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), __uint_as_float(cls));
-                if (S.n_classes > 1u) st.cls[item] = (uint8_t)cls;  // what the class sort reads: 1 byte per path instead of a 16-byte record
+                uint32_t cls = (S.n_classes > 1u && h.inst != 0xffffffffu) ? S.inst[h.inst].pad[0] : 0u;
+                if (split) {
+                    // The path integrator's queue of a scene with one shading class, split by what src/pathintegrator.rs does with
+                    // the result (class 1 = kept for k_shade, 0 = dropped; k_class_count / _scan / _scatter then list the kept
+                    // positions, in queue order).  A hit is kept: a surface with lobes is shaded (:31-71), an emitter adds its
+                    // emission and the empty light estimate and ends.  A miss that sees the environment (the first bounce or after a
+                    // specular one, :19-22) is kept: it adds the environment and ends.  Any other miss adds nothing (`break` at
+                    // :25-27 with nothing before it) and is dropped — in an open scene most of a bounce's queue; so is a miss of the
+                    // first bounce under a black environment: L = 0 + 1 * 0 there, which is what k_raygen left in L.  (After a
+                    // specular bounce under a black environment beta may be infinite: beta * 0 is kept for k_shade to add.)
+                    cls = 1u;
+                    if (h.inst == 0xffffffffu) {
+                        const bool specular = (__float_as_uint(q0[item].w) >> 31) != 0u;  // the path record's flag, read again: misses only
+                        cls = (specular || ((split & 2u) && S.has_env != 0u)) ? 1u : 0u;
+                    }
+                }
+                if (!split || cls) st.hit[item] = make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), __uint_as_float(split ? 0u : cls));
+                if (S.n_classes > 1u || split) st.cls[item] = (uint8_t)cls;  // what the class sort reads: 1 byte per path instead of a 16-byte record
                 walk.mode = PBRS_WALK_IDLE;
             }
             if (work.left()) {
                 uint32_t idx = wave_fetch(work, walk.mode == PBRS_WALK_IDLE, next, n);
                 if (idx != 0xffffffffu) {
                     if (indirect) idx = indirect[idx];
-                    item = idx;
                     stk.item = idx;
                     const float4 a = q0[idx], b = q1[idx];
+                    item = idx;
                     walk.start(S, xyz(a), xyz(b), pn_inf(), stk);
                     nrays++;
                 }
@@ -514,7 +529,8 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
     uint32_t next_spec = 0;
     if (valid) {
         const uint32_t set = bounce & 1u;
-        // several shading classes: lanes take the paths in class order (k_class_sort), so that a wave runs one material's code
+        // several shading classes: lanes take the paths in class order (k_class_sort), so that a wave runs one material's code; a
+        // queue k_extend split into kept and dropped paths: lanes take the kept positions (class 1 of a class-major order)
         const uint32_t src = sorted ? st.perm[i] : i;
         const float4 r0 = st.q[set][0][src], r1 = st.q[set][1][src], r2 = st.q[set][2][src], rh = st.hit[src];
         slot = __float_as_uint(r0.w) & PBRS_SLOT_MASK;
@@ -986,7 +1002,8 @@ __global__ void __launch_bounds__(256) k_class_count(PathState st, const uint32_
     if (threadIdx.x < PBRS_MAX_CLASSES) st.tile_hist[blockIdx.x * PBRS_MAX_CLASSES + threadIdx.x] = s_tot[threadIdx.x];
 }
 // One block of PBRS_MAX_CLASSES waves: wave c turns class c's per-tile counts into offsets inside the class.
-__global__ void __launch_bounds__(64 * PBRS_MAX_CLASSES) k_class_scan(PathState st, const uint32_t* count, uint32_t n_direct, uint32_t last) {
+// `acc` (optional): adds (paths of class `last`, paths in all) to two counters — what a queue split kept (pbrs_gpu.hip, split_decision).
+__global__ void __launch_bounds__(64 * PBRS_MAX_CLASSES) k_class_scan(PathState st, const uint32_t* count, uint32_t n_direct, uint32_t last, unsigned long long* acc) {
     const uint32_t n = count ? *count : n_direct;
     const uint32_t n_tiles = (n + PBRS_SORT_TILE - 1u) / PBRS_SORT_TILE;
     const uint32_t c = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1014,6 +1031,10 @@ __global__ void __launch_bounds__(64 * PBRS_MAX_CLASSES) k_class_scan(PathState 
         }
         st.class_range[PBRS_MAX_CLASSES] = make_uint2(0u, run);  // every class but `last`
         if (last < PBRS_MAX_CLASSES) st.class_range[last] = make_uint2(run, run + s_total[last]);
+        if (acc && last < PBRS_MAX_CLASSES) {
+            atomicAdd(acc, (unsigned long long)s_total[last]);
+            atomicAdd(acc + 1, (unsigned long long)n);
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_class_scatter(PathState st, const uint32_t* count, uint32_t n_direct) {

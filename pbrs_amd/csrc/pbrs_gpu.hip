@@ -27,8 +27,11 @@ constexpr uint32_t kMaxDepth = 64;
 constexpr uint32_t kHeadWords = PBRS_WORK_HEADS * PBRS_WORK_HEAD_STRIDE;
 // per bounce: act, ns (u64), the slow-list lengths of k_extend and k_shadow; then four sets of work heads (the two stages, and
 // the binary-walk launches that work off their slow lists)
-constexpr uint32_t kCounterWords = (5 + 4 * kHeadWords) * (kMaxDepth + 2);
-constexpr uint32_t kSlowGrid = 64;  // blocks of a binary-walk launch over a slow list (empty in nearly every launch)
+constexpr uint32_t kCounterWords = (7 + 4 * kHeadWords) * (kMaxDepth + 2);  // ... and k_extend's split counts (u64)
+constexpr uint32_t kSlowGrid = 64;
+#ifndef PBRS_SPLIT_KEEP_PERCENT
+#define PBRS_SPLIT_KEEP_PERCENT 85u  // k_extend's queue split stays on where it keeps at most this share of a pass's rays for k_shade
+#endif  // blocks of a binary-walk launch over a slow list (empty in nearly every launch)
 constexpr uint32_t kStreamGridCap = 4096;  // blocks of k_nee_resolve, whose work is counted on the device (kernels.h)
 constexpr uint32_t kPersistentBlocks = PBRS_PERSISTENT_BLOCKS;  // 256 CUs x up to 6 resident 256-thread blocks (VGPR/LDS permitting)
 constexpr size_t kLdsBytesPerCU = 160 * 1024;
@@ -89,6 +92,11 @@ struct pbrs_ctx {
     uint32_t shade_spec = 0;       // PBRS_SHADE_*: what k_shade<PATH> may leave out for this scene
     bool long_walks = false;       // a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: the PBRS_FEAT_LONG_WALKS kernels
     bool shadow_flat = false;      // k_shadow scans the TLAS leaves (up to PBRS_FLAT_TLAS_MAX_ANYHIT instances; k_extend: S.features)
+    bool split_queue = true;       // k_extend splits the path integrator's queue of one-class scenes (shaded / terminal / dropped); PBRS_SPLIT_QUEUE=0 in developer builds
+    // ... which pays where many paths are dropped (an open scene: C4 shades in 84 instead of 117 ms per frame) and costs where
+    // none are (a closed box: the gathered records cost C2 4 %).  Decided once per uploaded scene, from the counts of the first
+    // pass rendered with the path integrator: 0 = not yet, 1 = split, 2 = do not.  The image does not depend on it.
+    int split_decision = 0;
     bool wide_extend = false, wide_shadow = false;  // the stage runs the walks over four-wide nodes (device/wide.h), the binary walks after it for what they refuse
     uint32_t* slow = nullptr;      // 2 * cap_slots: queue positions a wide-walk kernel handed to the binary-walk kernel
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
@@ -161,8 +169,8 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
         // q[2][3], hit, L, nee[3]: one float4 per path each; sr[3]: two per path; occ: two bytes; nee queue: one word
         const size_t n_tiles = n_slots / PBRS_SORT_TILE + 1;
         const size_t sort_bytes = align(n_tiles * PBRS_MAX_CLASSES * sizeof(uint32_t)) + align((PBRS_MAX_CLASSES + 1) * sizeof(uint2));
-        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + 2 * align(n_slots * sizeof(uint32_t)) + sort_bytes + align(n_slots) +
-                             align(2 * n_slots * sizeof(uint32_t));
+        const size_t total = (6 + 1 + 1 + 3) * v16 + 3 * 2 * v16 + align(2 * n_slots) + align(n_slots * sizeof(uint32_t)) + align(n_slots * sizeof(uint32_t)) +
+                             sort_bytes + align(n_slots) + align(2 * n_slots * sizeof(uint32_t));
         hipError_t e = hipMalloc(&c->state_mem, total);
         if (e != hipSuccess) {
             c->state_mem = nullptr;
@@ -357,13 +365,14 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
 // exists for the full set only.  k_shadow never evaluates shading frames, so only PBRS_FEAT_ANALYTIC selects it.
 // `wide`: the walks over four-wide nodes (scenes with a scanned TLAS); `indirect` / `slow_*`: see kernels.h.
 void launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* heads,
-                   const uint32_t* indirect, uint32_t* slow_list, uint32_t* slow_count) {
+                   const uint32_t* indirect, uint32_t* slow_list, uint32_t* slow_count, uint32_t split) {
     // k_extend scans the TLAS leaves only up to PBRS_FLAT_TLAS_MAX instances (S.features); the leaf copies may exist for
     // k_shadow alone, and the instrumented variant, which carries every feature, must then walk the tree like the timed one
     DevScene S = c->S;
     if (!(S.features & PBRS_FEAT_FLAT_TLAS)) S.n_flat = 0u;
 #define PBRS_LAUNCH_EXTEND(ST, F) \
-    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt, indirect, slow_list, slow_count)
+    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt, indirect, slow_list, slow_count, \
+                       split)
     if (stats) {
         PBRS_LAUNCH_EXTEND(true, PBRS_FEAT_ALL);
         return;
@@ -458,7 +467,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     // work-fetch heads of k_extend / k_shadow: kHeadWords words per bounce (one head per queue segment, kernels.h)
     uint32_t* slowx = c->counters + 3 * stride;  // slow-list lengths per bounce: k_extend's, k_shadow's
     uint32_t* slows = slowx + stride;
-    uint32_t* xhead = c->counters + 5 * stride;
+    uint32_t* xhead = c->counters + 7 * stride;
     uint32_t* shead = xhead + stride * kHeadWords;
     uint32_t* xhead2 = shead + stride * kHeadWords;  // the binary-walk launches over the slow lists
     uint32_t* shead2 = xhead2 + stride * kHeadWords;
@@ -479,9 +488,12 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         // queue length of bounce 0 is the pass size, later ones are counted on the device
         const uint32_t* cnt_in = b == 0 ? nullptr : act + b;
         if (tm.begin(1)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        launch_extend(c, stats, wide_x, pgrid, wide_x ? lds_wx : lds, b & 1u, cnt_in, N, xhead + b * kHeadWords, nullptr, c->slow, slowx + b);
+        // the path integrator on a scene with one shading class (no class sort): k_extend splits its queue into the hits k_shade
+        // shades, the paths that only end (emitter hits, misses that see the environment) and the misses nothing happens to
+        const uint32_t qsplit = (rc.integrator == PBRS_INTEGRATOR_PATH && c->S.n_classes <= 1u && c->split_queue && c->split_decision != 2) ? (1u | (b == 0 ? 2u : 0u)) : 0u;
+        launch_extend(c, stats, wide_x, pgrid, wide_x ? lds_wx : lds, b & 1u, cnt_in, N, xhead + b * kHeadWords, nullptr, c->slow, slowx + b, qsplit);
         if (wide_x)  // what the wide walks refused (rays outside the guarded range of the division-free box test, overlong stacks)
-            launch_extend(c, false, false, pgrid < kSlowGrid ? pgrid : kSlowGrid, lds, b & 1u, slowx + b, 0u, xhead2 + b * kHeadWords, c->slow, nullptr, nullptr);
+            launch_extend(c, false, false, pgrid < kSlowGrid ? pgrid : kSlowGrid, lds, b & 1u, slowx + b, 0u, xhead2 + b * kHeadWords, c->slow, nullptr, nullptr, qsplit);
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
         // several shading classes (and an integrator that shades): order the queue by class first; counted as shade time
@@ -490,18 +502,23 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         // queue, so that the class gets a launch of that variant and the other classes one of the general kernel
         const bool split = sorted && c->lambert_class && c->split_lambert && !c->textured && !c->fourier && rc.integrator == PBRS_INTEGRATOR_PATH;
         const uint32_t n_tiles = (N + PBRS_SORT_TILE - 1) / PBRS_SORT_TILE;
-        if (split) {
+        if (split || qsplit) {  // class-major over the whole queue; a queue k_extend split: class 1 = the kept paths, last
             hipLaunchKernelGGL(k_class_count, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
-            hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64 * PBRS_MAX_CLASSES), 0, c->stream, c->st, cnt_in, N, c->lambert_class);
+            hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64 * PBRS_MAX_CLASSES), 0, c->stream, c->st, cnt_in, N, qsplit ? 1u : c->lambert_class,
+                               (qsplit && c->split_decision == 0) ? c->bounce_acc + 2 * PBRS_STATS_MAX_BOUNCES : nullptr);
             hipLaunchKernelGGL(k_class_scatter, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
         } else if (sorted) {
             hipLaunchKernelGGL(k_class_sort, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
         }
         {
 #define PBRS_LAUNCH_SHADE(I, T, SP)                                                                                                       \
-    hipLaunchKernelGGL((k_shade<I, T, SP>), dim3(grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, cnt_in, N, act + b + 1, neeq, ns + b, sorted, \
-                       shade_range)
-            const uint2* shade_range = nullptr;
+    hipLaunchKernelGGL((k_shade<I, T, SP>), dim3(shade_grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, shade_count, N, act + b + 1, neeq, ns + b, \
+                       sorted | split_sorted, shade_range)
+            const uint32_t shade_grid = grid;
+            const uint2* shade_range = qsplit ? c->st.class_range + 1 : nullptr;  // a split queue: the kept paths
+            const uint32_t split_sorted = qsplit ? 1u : 0u;
+            const uint32_t* shade_count = cnt_in;
+            {
             const bool direct = rc.integrator == PBRS_INTEGRATOR_DIRECT;
             if (rc.integrator == PBRS_INTEGRATOR_MATERIALS) {
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false, 0u);
@@ -536,6 +553,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
                     default: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, 0u); break;
                 }
             }
+            }
 #undef PBRS_LAUNCH_SHADE
         }
         tm.end();
@@ -545,6 +563,16 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
             launch_shadow(c, false, false, pgrid < kSlowGrid ? pgrid : kSlowGrid, lds, slows + b, shead2 + b * kHeadWords, c->slow, nullptr, nullptr);
         hipLaunchKernelGGL(k_nee_resolve, dim3(sgrid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
         tm.end();
+    }
+    if (c->split_decision == 0 && rc.integrator == PBRS_INTEGRATOR_PATH && c->S.n_classes <= 1u && c->split_queue && n_bounces > 0) {
+        // the first pass of this scene through the path integrator: how much of its queues did the split keep for k_shade?
+        // (one synchronisation per uploaded scene; the image does not depend on the answer)
+        unsigned long long kept_all[2] = {0, 0};
+        unsigned long long* acc = c->bounce_acc + 2 * PBRS_STATS_MAX_BOUNCES;
+        HIPCHK(c, hipMemcpyAsync(kept_all, acc, sizeof kept_all, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemsetAsync(acc, 0, sizeof kept_all, c->stream));
+        c->split_decision = (kept_all[0] * 100ull <= kept_all[1] * PBRS_SPLIT_KEEP_PERCENT) ? 1 : 2;
     }
     if (stats)  // queue sizes of this pass, bounce by bounce (the counters are cleared at the start of every pass)
         hipLaunchKernelGGL(k_sum_bounce_counts, dim3(1), dim3(64), 0, c->stream, act, ns, N, n_bounces, c->bounce_acc);
@@ -692,6 +720,7 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     c->stream = c->own_stream;
     if (const char* e = dev_env("PBRS_SORT_CLASSES")) c->sort_classes = std::atoi(e) != 0;
     if (const char* e = dev_env("PBRS_SPLIT_LAMBERT")) c->split_lambert = std::atoi(e) != 0;
+    if (const char* e = dev_env("PBRS_SPLIT_QUEUE")) c->split_queue = std::atoi(e) != 0;
     for (int k = 0; ok && k < 2; ++k) {
         hipEvent_t ev = nullptr;
         ok = hipEventCreate(&ev) == hipSuccess;
@@ -700,7 +729,8 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&c->nonfinite), sizeof(unsigned long long)) == hipSuccess &&
-         hipMalloc(reinterpret_cast<void**>(&c->bounce_acc), 2 * PBRS_STATS_MAX_BOUNCES * sizeof(unsigned long long)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&c->bounce_acc), (2 * PBRS_STATS_MAX_BOUNCES + 2) * sizeof(unsigned long long)) == hipSuccess &&
+         hipMemset(c->bounce_acc, 0, (2 * PBRS_STATS_MAX_BOUNCES + 2) * sizeof(unsigned long long)) == hipSuccess &&
          hipMemset(c->nonfinite, 0, sizeof(unsigned long long)) == hipSuccess;
     ok = ok && configure_kernels(c) == PBRS_OK;
     if (!ok) {
@@ -1039,6 +1069,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     c->has_vis_records = vis_records;
     c->stack_depth = depth;
     c->has_scene = true;
+    c->split_decision = 0;
     return PBRS_OK;
 }
 
