@@ -928,6 +928,7 @@ __global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, Pat
 // Class sizes of the queue positions [base, end) into s_tot[] (zeroed, block-wide).  Sixteen ballots per 64 paths, lane c of a
 // wave keeping class c's count, and one LDS add per lane at the end: one LDS atomic per PATH on sixteen words at most was
 // what the counting pass spent its time on (0.39 ms per 200 M paths reading bytes, as much as when it read 16-byte records).
+template <uint32_t NC>  // classes that occur (16, or 2 for a queue split into kept and dropped paths)
 PD void tile_class_histogram(const uint8_t* cls, uint32_t base, uint32_t end, uint32_t* s_tot) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t mine = 0;
@@ -935,12 +936,12 @@ PD void tile_class_histogram(const uint8_t* cls, uint32_t base, uint32_t end, ui
         const uint32_t i = it + threadIdx.x;
         const uint32_t c = i < end ? ((uint32_t)cls[i] & (PBRS_MAX_CLASSES - 1u)) : 0xffffffffu;
 #pragma unroll
-        for (uint32_t k = 0; k < PBRS_MAX_CLASSES; ++k) {
+        for (uint32_t k = 0; k < NC; ++k) {
             const uint32_t nk = (uint32_t)__popcll(__ballot(c == k));
             if (lane == k) mine += nk;
         }
     }
-    if (lane < PBRS_MAX_CLASSES && mine) atomicAdd(&s_tot[lane], mine);
+    if (lane < NC && mine) atomicAdd(&s_tot[lane], mine);
 }
 __global__ void __launch_bounds__(256) k_class_sort(PathState st, const uint32_t* count, uint32_t n_direct) {
     const uint32_t n = count ? *count : n_direct;
@@ -952,7 +953,7 @@ __global__ void __launch_bounds__(256) k_class_sort(PathState st, const uint32_t
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] = 0u;
     __syncthreads();
-    tile_class_histogram(st.cls, base, end, s_tot);
+    tile_class_histogram<PBRS_MAX_CLASSES>(st.cls, base, end, s_tot);
     __syncthreads();
     if (threadIdx.x == 0) {  // exclusive prefix over the classes
         uint32_t run = base;
@@ -989,6 +990,7 @@ __global__ void __launch_bounds__(256) k_class_sort(PathState st, const uint32_t
 // the same stable counting sort, over the whole queue — per-tile histograms (k_class_count), their prefix over the tiles per
 // class (k_class_scan, one block), then the scatter (k_class_scatter).  Classes come in the order 0, 1, ... with class `last`
 // moved to the end, so that "all classes but `last`" is one range of lanes too: class_range[PBRS_MAX_CLASSES].
+template <uint32_t NC>
 __global__ void __launch_bounds__(256) k_class_count(PathState st, const uint32_t* count, uint32_t n_direct) {
     const uint32_t n = count ? *count : n_direct;
     const uint32_t base = blockIdx.x * PBRS_SORT_TILE;
@@ -997,7 +999,7 @@ __global__ void __launch_bounds__(256) k_class_count(PathState st, const uint32_
     __shared__ uint32_t s_tot[PBRS_MAX_CLASSES];
     if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] = 0u;
     __syncthreads();
-    tile_class_histogram(st.cls, base, end, s_tot);
+    tile_class_histogram<NC>(st.cls, base, end, s_tot);
     __syncthreads();
     if (threadIdx.x < PBRS_MAX_CLASSES) st.tile_hist[blockIdx.x * PBRS_MAX_CLASSES + threadIdx.x] = s_tot[threadIdx.x];
 }
@@ -1037,6 +1039,7 @@ __global__ void __launch_bounds__(64 * PBRS_MAX_CLASSES) k_class_scan(PathState 
         }
     }
 }
+template <uint32_t NC>
 __global__ void __launch_bounds__(256) k_class_scatter(PathState st, const uint32_t* count, uint32_t n_direct) {
     const uint32_t n = count ? *count : n_direct;
     const uint32_t base = blockIdx.x * PBRS_SORT_TILE;
@@ -1052,19 +1055,20 @@ __global__ void __launch_bounds__(256) k_class_scatter(PathState st, const uint3
         const bool valid = i < end;
         const uint32_t cls = valid ? ((uint32_t)st.cls[i] & (PBRS_MAX_CLASSES - 1u)) : 0xffffffffu;
         uint32_t rank = 0;
-        for (uint32_t c = 0; c < PBRS_MAX_CLASSES; ++c) {
+#pragma unroll
+        for (uint32_t c = 0; c < NC; ++c) {
             const uint64_t m = __ballot(cls == c);
             if (cls == c) rank = lane_prefix(m);
             if (lane == 0) s_wave[wave][c] = (uint32_t)__popcll(m);
         }
         __syncthreads();
-        if (valid) {
+        if (valid && !(NC == 2u && cls == 0u)) {  // two classes: a queue split into dropped (0) and kept (1) paths, only the kept are listed
             uint32_t pos = s_tot[cls] + rank;
             for (uint32_t w = 0; w < wave; ++w) pos += s_wave[w][cls];
             st.perm[pos] = i;
         }
         __syncthreads();
-        if (threadIdx.x < PBRS_MAX_CLASSES) s_tot[threadIdx.x] += s_wave[0][threadIdx.x] + s_wave[1][threadIdx.x] + s_wave[2][threadIdx.x] + s_wave[3][threadIdx.x];
+        if (threadIdx.x < NC) s_tot[threadIdx.x] += s_wave[0][threadIdx.x] + s_wave[1][threadIdx.x] + s_wave[2][threadIdx.x] + s_wave[3][threadIdx.x];
         __syncthreads();
     }
 }

@@ -503,10 +503,12 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         const bool split = sorted && c->lambert_class && c->split_lambert && !c->textured && !c->fourier && rc.integrator == PBRS_INTEGRATOR_PATH;
         const uint32_t n_tiles = (N + PBRS_SORT_TILE - 1) / PBRS_SORT_TILE;
         if (split || qsplit) {  // class-major over the whole queue; a queue k_extend split: class 1 = the kept paths, last
-            hipLaunchKernelGGL(k_class_count, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
+            if (qsplit) hipLaunchKernelGGL(k_class_count<2u>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
+            else hipLaunchKernelGGL(k_class_count<PBRS_MAX_CLASSES>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
             hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64 * PBRS_MAX_CLASSES), 0, c->stream, c->st, cnt_in, N, qsplit ? 1u : c->lambert_class,
                                (qsplit && c->split_decision == 0) ? c->bounce_acc + 2 * PBRS_STATS_MAX_BOUNCES : nullptr);
-            hipLaunchKernelGGL(k_class_scatter, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
+            if (qsplit) hipLaunchKernelGGL(k_class_scatter<2u>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
+            else hipLaunchKernelGGL(k_class_scatter<PBRS_MAX_CLASSES>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
         } else if (sorted) {
             hipLaunchKernelGGL(k_class_sort, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
         }
