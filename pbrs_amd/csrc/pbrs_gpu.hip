@@ -961,7 +961,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
                 if (it == wide_of_root.end()) it = wide_of_root.emplace(in.blas_root, build_wide(nodes, in.blas_root, wide, 0u, levels)).first;
                 in.pad[1] = it->second;
             }
-            if (wide.size() >= 0x7fffffffull) return fail(c, PBRS_E_LIMIT, "too many BVH nodes");
+            if (wide.size() * sizeof(pbrs_wnode) >= (1ull << 32)) return fail(c, PBRS_E_LIMIT, "too many BVH nodes (wide nodes are addressed with 32-bit byte offsets)");
             const pbrs_wnode* dev = nullptr;
             if ((rc = upload(c, wide.data(), wide.size(), &dev))) return rc;
             S.wnodes = dev;
