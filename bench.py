@@ -29,9 +29,10 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 DEFAULT_CONFIG = "c4"
-CPU_SAMPLES = {"c1": (256, 256, 4), "c2": (512, 512, 4), "c3": (512, 512, 4), "c4": (960, 540, 4), "c5": (960, 540, 4)}
+CPU_SAMPLES = {"c1": (256, 256, 4), "c2": (512, 512, 4), "c3": (512, 512, 4), "c4": (960, 540, 4), "c5": (960, 540, 4), "c4xl": (960, 540, 4)}
 # the window of the timed frame the oracle re-renders (x0, y0, w, h), chosen where each scene has its mixed materials / deep BLAS
-PARITY_WINDOWS = {"c1": (96, 120, 64, 8), "c2": (480, 500, 64, 8), "c3": (300, 700, 64, 8), "c4": (900, 600, 64, 8), "c5": (1800, 1400, 64, 8)}
+PARITY_WINDOWS = {"c1": (96, 120, 64, 8), "c2": (480, 500, 64, 8), "c3": (300, 700, 64, 8), "c4": (900, 600, 64, 8), "c5": (1800, 1400, 64, 8),
+                  "c4xl": (900, 600, 64, 8)}
 # configs timed on a stated slice of their spp when they ride along in `other_configs` (samples are i.i.d. passes: SURVEY.md §8d)
 ALSO_STRATA = {"c5": (8, 8)}
 
@@ -41,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default=DEFAULT_CONFIG, help="c1..c5 (BASELINE.json configs[0..4]); default c4 = the north-star workload")
+    ap.add_argument("--config", default=DEFAULT_CONFIG, help="c1..c5 (BASELINE.json configs[0..4]); default c4 = the north-star workload; c4xl = C4's generator at 16.8 M triangles (not a BASELINE config)")
     ap.add_argument("--also", default=None, help="comma-separated configs timed after the main one at N = 1 (default: c2,c3,c5 when --config is c4; c5 on a 64-spp slice)")
     ap.add_argument("--also-steps", type=int, default=2)
     ap.add_argument("--width", type=int, default=None)
@@ -273,10 +274,13 @@ class Workload:
             "unit": "Msamples/s",
             "steps": steps,
             "ms_per_step": elapsed / steps * 1e3,
-            "config": {"workload": f"BASELINE configs[{int(self.name[1]) - 1}] ({self.name}): {W}x{H}, {spp} spp ({sx}x{sy} strata), "
+            "config": {"workload": (f"BASELINE configs[{int(self.name[1]) - 1}] ({self.name})" if self.name in ("c1", "c2", "c3", "c4", "c5") else
+                                    f"{self.name} (not a BASELINE config: C4's generator at 16.8 M triangles, a scene ten times the Infinity Cache)") +
+                                   f": {W}x{H}, {spp} spp ({sx}x{sy} strata), "
                                    f"path depth {depth}, frame tiled over {world} GPU(s) in interleaved {self.tiling.BAND_ROWS}-row bands",
                        "scene": self.name, "width": W, "height": H, "spp": spp, "depth": depth, "seed": self.args.seed,
-                       "integrator": self.args.integrator, "scene_bytes_in_hbm": self.hs.nbytes, "full_size": self.full_size},
+                       "integrator": self.args.integrator, "scene_bytes_in_hbm": self.hs.nbytes,
+                       "full_size": self.full_size and self.name in ("c1", "c2", "c3", "c4", "c5")},
             "mrays_per_s": rays_per_step * steps / elapsed / 1e6,
             "rays_per_step": rays_per_step,
             "closest_rays_per_step": counts[0],

@@ -237,6 +237,9 @@ CONFIGS = {
     "c3": (cornell_scene, {"variant": "specular"}, 1024, 1024, 32, 32, 8),
     "c4": (terrain_scene, {}, 1920, 1080, 32, 16, 8),
     "c5": (many_lights_scene, {}, 3840, 2160, 64, 64, 8),
+    # not a BASELINE config: C4's generator on a 2048 x 4096 grid (16.8 M triangles, ~2.4 GB flattened: ten times the Infinity
+    # Cache) at 64 spp — what the traversal kernels do when node fetches really go to HBM (bench.py --config c4xl)
+    "c4xl": (terrain_scene, {"nx": 2048, "nz": 4096}, 1920, 1080, 8, 8, 8),
 }
 
 
