@@ -201,6 +201,44 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #ifndef PBRS_SHD_LEAF_MIN
 #define PBRS_SHD_LEAF_MIN 8
 #endif
+// Developer probe (tools/trav_probe.py; -DPBRS_PROBE_TRAV builds only): what the traversal loops execute, summed over a launch's
+// waves.  kp[]: 0 loop rounds, 1 refills, 2 rays started, 3 boundary-step executions, 4 lanes in them, 5 / 6 / 7 lanes in a round's first /
+// second / third node step, 8 leaf-step executions, 9 lanes holding a leaf in them, 10 lanes with a walk at the start of a round,
+// 11 rounds whose first node step had a lane; then the walks' own eight counters (traverse.h).  [0]: k_extend, [1]: k_shadow.
+#ifdef PBRS_PROBE_TRAV
+__device__ unsigned long long g_trav_probe[2][24];
+#define PBRS_KP_DECL(walk)      \
+    uint32_t kp[16];            \
+    for (int k_ = 0; k_ < 16; ++k_) kp[k_] = 0; \
+    for (int k_ = 0; k_ < PBRS_TP_N; ++k_) walk.pr[k_] = 0
+#define PBRS_KP_LANE(i, cond)  \
+    do {                       \
+        if (cond) kp[i]++;     \
+    } while (0)
+#define PBRS_KP_WAVE(i) PBRS_KP_LANE(i, (threadIdx.x & 63u) == 0u)  /* wave-uniform control flow only */
+PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
+    for (int k = 0; k < 24; ++k) {
+        uint32_t v = k < 16 ? kp[k] : pr[k - 16];
+        unsigned long long t = v;
+        for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o, 64);
+        if ((threadIdx.x & 63u) == 0u && t) atomicAdd(&g_trav_probe[which][k], t);
+    }
+}
+#define PBRS_KP_FLUSH(which, walk) trav_probe_flush(which, kp, walk.pr)
+#else
+#define PBRS_KP_DECL(walk) \
+    do {                   \
+    } while (0)
+#define PBRS_KP_LANE(i, cond) \
+    do {                      \
+    } while (0)
+#define PBRS_KP_WAVE(i) \
+    do {                \
+    } while (0)
+#define PBRS_KP_FLUSH(which, walk) \
+    do {                           \
+    } while (0)
+#endif
 // Scenes with long walks (a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: PBRS_FEAT_LONG_WALKS) take PBRS_NODE_STEPS_LONG
 // node steps per loop round: most rounds of a deep walk are node steps, and the checks around them (who waits at a
 // boundary, who holds a leaf, who is done) then run a third as often.  C4 (23 levels), ms per frame extend / shadow at
@@ -208,24 +246,34 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 // C3 -1 %: the later steps run at few lanes) and keep one.
 #define PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS)                            \
     do {                                                                           \
-        _Pragma("unroll") for (uint32_t k_ = 1; k_ < (NSTEPS); ++k_)               \
+        _Pragma("unroll") for (uint32_t k_ = 1; k_ < (NSTEPS); ++k_) {             \
+            PBRS_KP_LANE(5 + (k_ < 2u ? k_ : 2u), walk.mode == PBRS_WALK_NODE);    \
             if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);          \
+        }                                                                          \
     } while (0)
 #define PBRS_STEP_WALK(walk, S, stk, cnt, XFER_MIN, LEAF_MIN, NSTEPS)                                                  \
     do {                                                                                                       \
+        PBRS_KP_WAVE(0);                                                                                       \
+        PBRS_KP_LANE(10, walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER); \
         const uint32_t nx = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_XFER));                         \
         if (nx) {                                                                                              \
             if (nx >= XFER_MIN || __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF) == 0) { \
                 PBRS_PROBE_XFER_COUNT(cnt);                                                                    \
+                PBRS_KP_WAVE(3);                                                                               \
+                PBRS_KP_LANE(4, walk.mode == PBRS_WALK_XFER);                                                  \
                 if (walk.mode == PBRS_WALK_XFER) walk.xfer_step(S, stk, cnt);                                   \
             }                                                                                                  \
         }                                                                                                      \
         PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                                      \
+        PBRS_KP_LANE(5, walk.mode == PBRS_WALK_NODE);                                                          \
+        if (__ballot(walk.mode == PBRS_WALK_NODE)) PBRS_KP_WAVE(11);                                           \
         if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                                          \
         PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS);                                                              \
         const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                         \
         if (nl && (nl >= LEAF_MIN || __ballot(walk.mode == PBRS_WALK_NODE) == 0)) {                            \
             PBRS_PROBE_LEAF_COUNT(cnt);                                                                        \
+            PBRS_KP_WAVE(8);                                                                                   \
+            PBRS_KP_LANE(9, walk.mode == PBRS_WALK_LEAF);                                                      \
             walk.leaf_wave(S, cnt);                                                                            \
         }                                                                                                      \
     } while (0)
@@ -365,31 +413,43 @@ PD void wave_append_slow(bool slow, uint32_t item, uint32_t* list, uint32_t* cou
 #ifndef PBRS_WIDE_NODE_STEPS  // node steps per loop round of the wide walks in scenes with long walks
 #define PBRS_WIDE_NODE_STEPS 2u
 #endif
-template <bool WIDE, bool STATS, uint32_t FEAT>
+#ifndef PBRS_PAIR_EXTEND_WAVES  // ... and for the kernels that walk pair nodes
+#define PBRS_PAIR_EXTEND_WAVES 6
+#endif
+#ifndef PBRS_PAIR_SHADOW_WAVES
+#define PBRS_PAIR_SHADOW_WAVES 6
+#endif
+#ifndef PBRS_PAIR_NODE_STEPS
+#define PBRS_PAIR_NODE_STEPS 2u
+#endif
+template <uint32_t ARITY, bool STATS, uint32_t FEAT>  // ARITY 0: the binary walks
 struct ClosestSel {
-    typedef ClosestWalkW<FEAT> type;
+    typedef ClosestWalkW<FEAT, ARITY> type;
 };
 template <bool STATS, uint32_t FEAT>
-struct ClosestSel<false, STATS, FEAT> {
+struct ClosestSel<0u, STATS, FEAT> {
     typedef ClosestWalk<STATS, FEAT> type;
 };
-template <bool WIDE, bool STATS, uint32_t FEAT>
+template <uint32_t ARITY, bool STATS, uint32_t FEAT>
 struct AnySel {
-    typedef AnyWalkW<FEAT> type;
+    typedef AnyWalkW<FEAT, ARITY> type;
 };
 template <bool STATS, uint32_t FEAT>
-struct AnySel<false, STATS, FEAT> {
+struct AnySel<0u, STATS, FEAT> {
     typedef AnyWalk<STATS, FEAT> type;
 };
+#define PBRS_WALK_ARITY(STATS, FEAT) ((STATS) ? 0u : ((FEAT) & PBRS_FEAT_PAIR) ? 2u : ((FEAT) & PBRS_FEAT_WIDE) ? 4u : 0u)
+#define PBRS_WALK_NSTEPS(FEAT, ARITY) (!((FEAT) & PBRS_FEAT_LONG_WALKS) ? 1u : (ARITY) == 2u ? PBRS_PAIR_NODE_STEPS : (ARITY) == 4u ? PBRS_WIDE_NODE_STEPS : PBRS_NODE_STEPS_LONG)
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
 // handed a new ray at the next refill, the walks of the other lanes continue where they were.
 // `indirect` (binary-walk kernels working off a slow list): the queue positions to trace, `count` of them.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_EXTEND_WAVES : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES)
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_PAIR) ? PBRS_PAIR_EXTEND_WAVES : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_EXTEND_WAVES : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES)
     k_extend(DevScene S, PathState st, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect,
              uint32_t* slow_list, uint32_t* slow_count, uint32_t split) {
     extern __shared__ uint32_t lds_stack[];
-    constexpr bool WIDE = !STATS && (FEAT & PBRS_FEAT_WIDE) != 0u;
+    constexpr uint32_t ARITY = PBRS_WALK_ARITY(STATS, FEAT);
+    constexpr bool WIDE = ARITY != 0u;
     const uint32_t n = count ? *count : n_direct;
     const float4* q0 = st.q[set][0];
     const float4* q1 = st.q[set][1];
@@ -397,13 +457,15 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
-    typename ClosestSel<WIDE, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
+    typename ClosestSel<ARITY, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
     walk.mode = PBRS_WALK_IDLE;
+    PBRS_KP_DECL(walk);
     uint32_t item = 0;  // queue position of the lane's ray
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
         if ((uint32_t)__popcll(live) < S.refill_below) {
+            PBRS_KP_WAVE(1);
             if constexpr (WIDE) {
                 wave_append_slow(walk.mode == PBRS_WALK_SLOW, item, slow_list, slow_count);
                 if (walk.mode == PBRS_WALK_SLOW) walk.mode = PBRS_WALK_IDLE;
@@ -444,6 +506,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                     item = idx;
                     walk.start(S, xyz(a), xyz(b), pn_inf(), stk);
                     nrays++;
+                    PBRS_KP_LANE(2, true);
                 }
                 if constexpr (WIDE) walk.scan_wave(S, stk);
                 else walk.scan_wave(S, cnt);
@@ -457,11 +520,11 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                 break;
             }
         }
-        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN,
-                       (FEAT & PBRS_FEAT_LONG_WALKS) ? (WIDE ? PBRS_WIDE_NODE_STEPS : PBRS_NODE_STEPS_LONG) : 1u);
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY));
         if constexpr (WIDE) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
+    if (!STATS) PBRS_KP_FLUSH(0, walk);
 }
 
 // Developer probe (tools/shade_probe.py; -DPBRS_PROBE_SHADE builds only): wall cycles of k_shade's regions, summed per wave.
@@ -1076,23 +1139,26 @@ __global__ void __launch_bounds__(256) k_class_scatter(PathState st, const uint3
 // ---- shadow ----------------------------------------------------------------------------------------------------
 // One work item per shadow ray (persistent, same refill scheme as k_extend); writes one occlusion byte.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_SHADOW_WAVES : PBRS_SHADOW_WAVES)
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_PAIR) ? PBRS_PAIR_SHADOW_WAVES : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_SHADOW_WAVES : PBRS_SHADOW_WAVES)
     k_shadow(DevScene S, PathState st, const uint32_t* count, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect, uint32_t* slow_list,
              uint32_t* slow_count) {
     extern __shared__ uint32_t lds_stack[];
-    constexpr bool WIDE = !STATS && (FEAT & PBRS_FEAT_WIDE) != 0u;
+    constexpr uint32_t ARITY = PBRS_WALK_ARITY(STATS, FEAT);
+    constexpr bool WIDE = ARITY != 0u;
     const uint32_t n = indirect ? count[0] : count[1];  // a slow list's length, or the high half of the packed (nee paths, shadow rays) counter
     LaneStack stk{lds_stack + threadIdx.x, st.sr[0], st.sr[1], 0u};
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
-    typename AnySel<WIDE, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
+    typename AnySel<ARITY, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
     walk.mode = PBRS_WALK_IDLE;
+    PBRS_KP_DECL(walk);
     uint32_t item = 0, rec = 0;
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
         if ((uint32_t)__popcll(live) < S.refill_below) {
+            PBRS_KP_WAVE(1);
             if constexpr (WIDE) {
                 wave_append_slow(walk.mode == PBRS_WALK_SLOW, rec, slow_list, slow_count);
                 if (walk.mode == PBRS_WALK_SLOW) walk.mode = PBRS_WALK_IDLE;
@@ -1124,6 +1190,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                     item = __float_as_uint(q1.w);
                     walk.start(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, stk);
                     nrays++;
+                    PBRS_KP_LANE(2, true);
                 }
                 if constexpr (WIDE) walk.scan_wave(S, stk);
                 else walk.scan_wave(S, cnt);
@@ -1137,11 +1204,11 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                 break;
             }
         }
-        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN,
-                       (FEAT & PBRS_FEAT_LONG_WALKS) ? (WIDE ? PBRS_WIDE_NODE_STEPS : PBRS_NODE_STEPS_LONG) : 1u);
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY));
         if constexpr (WIDE) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, 0u);
+    if (!STATS) PBRS_KP_FLUSH(1, walk);
 }
 
 // The radiance add of uniform_sample_one_light / path_integrator for paths whose estimate had to wait for

@@ -55,6 +55,9 @@ struct DevScene {
     // and the entries a lane's stack may hold in the kernels that walk them (beyond that a ray goes to the binary-walk kernels)
     const pbrs_wnode* wnodes;
     uint32_t wide_cap;
+    // Kernels that walk pair nodes (PBRS_FEAT_PAIR) are launched with wnodes = the pair nodes, wide_cap = their stack rows, and
+    // the pair node of every mesh instance's root here (PBRS_WREF_NONE where the mesh is a single leaf)
+    const uint32_t* wroot;
 };
 
 // Scene features the traversal kernels are specialised on (pbrs_upload_scene derives them from the arrays it checks).
@@ -69,6 +72,7 @@ struct DevScene {
 #define PBRS_FEAT_ALL 7u
 #define PBRS_FEAT_LONG_WALKS 8u     // kernels only (not a property of the walks): several node steps per loop round (kernels.h)
 #define PBRS_FEAT_WIDE 16u          // kernels only: the walks over four-wide nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
+#define PBRS_FEAT_PAIR 32u          // kernels only: the same walks over pair nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
 #define PBRS_FLAT_TLAS_MIN 2u
 // Largest TLAS the wave scans instead of walking (tools/tlas_probe.py, C5's scene family at 960x540, ms per 64 spp, walk vs
 // scan): closest hit 4.84 / 4.74 at 20 instances, 5.10 / 5.28 at 24, 5.66 / 6.15 at 30 — the scan only filters there and every

@@ -23,6 +23,20 @@
 #pragma once
 #include "shapes.h"
 
+// Developer probe (tools/trav_probe.py; -DPBRS_PROBE_TRAV builds only): per-lane event counts of a walk — 0 node steps, 1 box
+// tests (a wide node's four count once), 2 of them failed, 3 BLAS leaves that came up, 4 of them with their own box passing,
+// 5 triangle tests run as a helper, 6 / 7 boundary steps in / out.
+#ifdef PBRS_PROBE_TRAV
+#define PBRS_TP_N 8
+#define PBRS_TP_FIELDS uint32_t pr[PBRS_TP_N];
+#define PBRS_TP(i) (this->pr[i]++)
+#else
+#define PBRS_TP_FIELDS
+#define PBRS_TP(i) \
+    do {           \
+    } while (0)
+#endif
+
 struct RaySpace {
     f3 o, d;
     double rx, ry, rz;  // rn64(1 / d)
@@ -332,6 +346,7 @@ struct ClosestWalk {
     uint32_t cand;        // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, moved;  // moved: C is not the world ray (inst_info bit 30: only its origin differs)
     uint32_t mode;
+    PBRS_TP_FIELDS
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         C = make_space(o, d, S.fast_slab != 0);
@@ -375,6 +390,7 @@ struct ClosestWalk {
 
     // One node: pop, box test, then push the children / hold the leaf / stop at the instance boundary.
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        PBRS_TP(0);
         if (in_blas && sp == blas_base) {  // the instance's entries are used up: leave it (xfer_step, or finish at retire time)
             mode = exit_mode();
             return;
@@ -397,7 +413,9 @@ struct ClosestWalk {
             }
         }
         const pbrs_node node = load_node(S.nodes + ni);
+        PBRS_TP(1);
         if (!slab_rs(node, C, lt)) {
+            PBRS_TP(2);
             if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = exit_mode();
             return;
         }
@@ -410,6 +428,8 @@ struct ClosestWalk {
             stk.put(sp++, left_first ? left : right);
             lt = in_blas ? mt : lt;
         } else if (in_blas) {
+            PBRS_TP(3);
+            PBRS_TP(4);
             leaf_a = node.a;
             leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
             if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
@@ -457,6 +477,7 @@ struct ClosestWalk {
     PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
         mode = PBRS_WALK_NODE;
         if (in_blas) {  // intersect_bvh / the shape returned (blas.rs:471-475) -> Instance::intersect -> bvh.rs:82
+            PBRS_TP(7);
             in_blas = false;
             leave_instance(S, stk, !moved ? PBRS_SPACE_WORLD : (inst_info & 0x40000000u) ? PBRS_SPACE_TRANSLATED : PBRS_SPACE_MOVED, C);
             meet_best(cnt);
@@ -469,6 +490,7 @@ struct ClosestWalk {
         // time, finish).  An analytic shape is visited here and now (analytic_visit).
         const pbrs_instance& in = S.inst[cur_inst];
         CNT(instances);
+        PBRS_TP(6);
         const uint32_t kind = inst_info;
         if ((FEAT & PBRS_FEAT_ANALYTIC) && kind != PBRS_SHAPE_MESH && kind != PBRS_SHAPE_TRIANGLE) {
             analytic_visit(S, in, kind, cnt);  // back at the TLAS already
@@ -552,6 +574,7 @@ struct ClosestWalk {
         const float hmt = (FEAT & PBRS_FEAT_SHADING_CHECK) ? sh.from_owner(mt) : 0.0f;
         float rt = pn_inf(), rb1 = 0.0f, rb2 = 0.0f;
         if (sh.helper()) {
+            PBRS_TP(5);
             pbrs_tri_verts tv = load_tri(S.tv + hti);
             CNT(triangles);
             TriHit h;
@@ -619,6 +642,7 @@ struct AnyWalk {
     uint32_t cand;  // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, occluded, moved;  // moved: C is not the world ray (inst_kind bit 8: only its origin differs)
     uint32_t mode;
+    PBRS_TP_FIELDS
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         C = make_space(o, d, S.fast_slab != 0);
@@ -656,6 +680,7 @@ struct AnyWalk {
         return nothing_above ? PBRS_WALK_DONE : PBRS_WALK_XFER;
     }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        PBRS_TP(0);
         if (in_blas && sp == blas_base) {
             mode = exit_mode();
             return;
@@ -679,7 +704,9 @@ struct AnyWalk {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
         }
+        PBRS_TP(1);
         if (!slab_rs(node, C, t_max)) {
+            PBRS_TP(2);
             if (PBRS_EARLY_OUT && in_blas && sp == blas_base) mode = exit_mode();
             return;
         }
@@ -689,6 +716,8 @@ struct AnyWalk {
             stk.put(sp++, left_first ? right : left);
             stk.put(sp++, left_first ? left : right);
         } else if (in_blas) {
+            PBRS_TP(3);
+            PBRS_TP(4);
             leaf_a = node.a;
             leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
             if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
@@ -702,12 +731,14 @@ struct AnyWalk {
     PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
         mode = PBRS_WALK_NODE;
         if (in_blas) {
+            PBRS_TP(7);
             in_blas = false;
             leave_instance(S, stk, !moved ? PBRS_SPACE_WORLD : (inst_kind & 0x100u) ? PBRS_SPACE_TRANSLATED : PBRS_SPACE_MOVED, C);
             return;
         }
         const pbrs_instance& in = S.inst[leaf_a];
         CNT(instances);
+        PBRS_TP(6);
         if ((FEAT & PBRS_FEAT_ANALYTIC) && inst_kind != PBRS_SHAPE_MESH && inst_kind != PBRS_SHAPE_TRIANGLE) {
             analytic_visit(S, in, cnt);  // Instance::occludes in one go; back at the TLAS, or occluded
             return;
@@ -737,6 +768,7 @@ struct AnyWalk {
         const uint32_t hti = sh.from_owner(leaf_a) + sh.k();
         bool hit = false;
         if (sh.helper()) {
+            PBRS_TP(5);
             pbrs_tri_verts tv = load_tri(S.tv + hti);
             hit = mesh_tri_pred(tv, ho, hd, htmax);
         }
@@ -808,12 +840,37 @@ struct AnyWalk {
 // the binary-walk kernel (kernels.h).
 #define PBRS_WALK_SLOW 6u
 #define PBRS_LEAF_UNVERIFIED 0xffffffffu
-template <uint32_t FEAT>
+// ARITY 4: four-wide nodes (DevScene::wnodes, an instance's root in pad[1]); ARITY 2: pair nodes (wide.h; the launch passes them
+// through the same DevScene fields: wnodes = the pair nodes, wide_cap = their stack rows, wroot[instance] = the root's pair node)
+template <uint32_t ARITY>
+struct WRaySel {
+    typedef WideRay type;
+};
+template <>
+struct WRaySel<2u> {
+    typedef PairRay type;
+};
+template <uint32_t ARITY>
+PD uint32_t wide_root_of(const DevScene& S, const pbrs_instance& in, uint32_t inst) {
+    return ARITY == 2u ? S.wroot[inst] : in.pad[1];
+}
+// One node step's test and pushes on pair nodes: the survivor visited first is returned (PBRS_WREF_NONE: neither passed),
+// the other one pushed; `false`: the push might not fit (the binary walk takes the ray).
+PD bool pair_node(const DevScene& S, uint32_t e, const RaySpace& C, const PairRay& W, float ext, LaneStack stk, int& sp, uint32_t& next) {
+    const PairTest t = pair_test(S.wnodes, e, C, W, ext);
+    next = t.pf ? t.first : t.ps ? t.second : PBRS_WREF_NONE;
+    if (t.pf && t.ps) {
+        if (sp + 1 > (int)S.wide_cap) return false;
+        stk.put(sp++, t.second);
+    }
+    return true;
+}
+template <uint32_t FEAT, uint32_t ARITY = 4u>
 struct ClosestWalkW : ClosestWalk<false, FEAT> {
     using B = ClosestWalk<false, FEAT>;
     using B::C; using B::best; using B::t_max; using B::lt; using B::mt; using B::mb1; using B::mb2; using B::mprim; using B::cur_inst;
     using B::inst_info; using B::leaf_a; using B::leaf_end; using B::sp; using B::blas_base; using B::cand; using B::in_blas; using B::moved; using B::mode;
-    WideRay W;
+    typename WRaySel<ARITY>::type W;
     uint32_t cur;  // wide node to take next (the nearest survivor of the last node step), or PBRS_WREF_NONE
     // A BLAS leaf held UNVERIFIED is (leaf_a = its node index, leaf_end = PBRS_LEAF_UNVERIFIED); the scanned TLAS leaf about to be
     // entered travels in leaf_a too.  The lane's column of the block's entry-distance table sits after the stack rows:
@@ -827,7 +884,12 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     }
     PD void scan_wave(const DevScene& S, LaneStack stk) {
         float* tl_block = reinterpret_cast<float*>(stk.base) - (threadIdx.x & (PBRS_TRAVERSAL_BLOCK - 1)) + S.wide_cap * PBRS_TRAVERSAL_BLOCK;
+#ifdef EXP_B
+        uint32_t tested_ = 0;
+        const uint32_t mine = FlatScan::run(S, mode == PBRS_WALK_SCAN, C, pn_inf(), tested_);
+#else
         const uint32_t mine = flat_scan_tlow(S, mode == PBRS_WALK_SCAN, C, tl_block);
+#endif
         if (mode == PBRS_WALK_SCAN) {
             cand = mine;
             mode = PBRS_WALK_NODE;
@@ -843,6 +905,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     // registers from living across it (the shared scan reads them from every lane of the wave, fresh or not).
     PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
+        PBRS_TP(0);
         uint32_t e = cur;
         if (e == PBRS_WREF_NONE) {
             if (!in_blas) {  // TLAS level: the next scanned leaf whose box the reference's test passes NOW (t_low <= min(hi_el, t_max))
@@ -869,18 +932,36 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             hold_leaf(e);
             return;
         }
-        const WideTest t = wide_test(S.wnodes, e, C, W, lt);  // inside a mesh lt == mt at every node (blas.rs:468), after the root
-        if (t.pass == 0u) {
-            if (sp == 0) mode = B::exit_mode();
-            return;
+        PBRS_TP(1);
+        if constexpr (ARITY == 2u) {
+            uint32_t first;
+            if (!pair_node(S, e, C, W, lt, stk, sp, first)) {
+                mode = PBRS_WALK_SLOW;
+                return;
+            }
+            if (first == PBRS_WREF_NONE) {
+                PBRS_TP(2);
+                if (sp == 0) mode = B::exit_mode();
+            } else if (first & PBRS_WREF_LEAF) {
+                hold_leaf(first);
+            } else {
+                cur = first;
+            }
+        } else {
+            const WideTest t = wide_test(S.wnodes, e, C, W, lt);  // inside a mesh lt == mt at every node (blas.rs:468), after the root
+            if (t.pass == 0u) {
+                PBRS_TP(2);
+                if (sp == 0) mode = B::exit_mode();
+                return;
+            }
+            if (sp + 3 > (int)S.wide_cap) {  // the pushes below might not fit: the binary walk takes this ray from its start
+                mode = PBRS_WALK_SLOW;
+                return;
+            }
+            const uint32_t first = wide_push(wide_order(t, C.d), stk, sp);  // the reference's order; its first is taken next, from the register
+            if (first & PBRS_WREF_LEAF) hold_leaf(first);
+            else cur = first;
         }
-        if (sp + 3 > (int)S.wide_cap) {  // the pushes below might not fit: the binary walk takes this ray from its start
-            mode = PBRS_WALK_SLOW;
-            return;
-        }
-        const uint32_t first = wide_push(wide_order(t, C.d), stk, sp);  // the reference's order; its first is taken next, from the register
-        if (first & PBRS_WREF_LEAF) hold_leaf(first);
-        else cur = first;
     }
     PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
         if (in_blas) {
@@ -890,6 +971,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             return;
         }
         mode = PBRS_WALK_NODE;
+        PBRS_TP(6);
         const pbrs_node leaf = load_node(S.nodes + S.flat_off + leaf_a);  // its box passed at this moment (node_step)
         cur_inst = leaf.a;
         const uint32_t kind = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
@@ -912,7 +994,8 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             }
             inst_info = kind | (in.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
             if (space == PBRS_SPACE_MOVED) W.set(C);  // a new direction (make_space has just computed its reciprocals); else the world's stands
-            if (in.pad[1] == PBRS_WREF_NONE) {  // the mesh is one leaf: its box is tested, against the incoming extent, with its triangles
+            const uint32_t wroot = wide_root_of<ARITY>(S, in, cur_inst);
+            if (wroot == PBRS_WREF_NONE) {  // the mesh is one leaf: its box is tested, against the incoming extent, with its triangles
                 hold_leaf(in.blas_root);
                 return;
             }
@@ -922,7 +1005,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
                 return;
             }
             lt = mt;
-            cur = in.pad[1];
+            cur = wroot;
         } else if (kind == PBRS_SHAPE_TRIANGLE) {
             inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
             leaf_a = in.blas_root;
@@ -934,10 +1017,16 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     // shared triangle tests (same values, same order).
     PD void leaf_wave(const DevScene& S, Cnt<false>& cnt) {
         if (mode == PBRS_WALK_LEAF && leaf_end == PBRS_LEAF_UNVERIFIED) {
+            PBRS_TP(3);
             const pbrs_node node = load_node(S.nodes + leaf_a);
             leaf_a = node.a;
             leaf_end = node.a;
+#ifdef EXP_A
+            if (pn_slab_filter(node.min[0], node.min[1], node.min[2], node.max[0], node.max[1], node.max[2], C.o.x, C.o.y, C.o.z, W.r32.x, W.r32.y, W.r32.z, lt)) {
+#else
             if (slab_rs(node, exact_space(C), lt)) {
+#endif
+                PBRS_TP(4);
                 leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
                 if (leaf_end == leaf_a) lt = mt;  // an empty leaf still runs blas.rs:468
             }
@@ -954,6 +1043,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
         const float hmt = (FEAT & PBRS_FEAT_SHADING_CHECK) ? sh.from_owner(mt) : 0.0f;
         float rt = pn_inf(), rb1 = 0.0f, rb2 = 0.0f;
         if (sh.helper()) {
+            PBRS_TP(5);
             pbrs_tri_verts tv = load_tri(S.tv + hti);
             TriHit h;
             constexpr bool need_bary = (FEAT & PBRS_FEAT_SHADING_CHECK) != 0u;
@@ -998,12 +1088,12 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     }
 };
 
-template <uint32_t FEAT>
+template <uint32_t FEAT, uint32_t ARITY = 4u>
 struct AnyWalkW : AnyWalk<false, FEAT> {
     using B = AnyWalk<false, FEAT>;
     using B::C; using B::t_max; using B::leaf_a; using B::leaf_end; using B::inst_kind; using B::sp; using B::blas_base; using B::cand; using B::in_blas;
     using B::occluded; using B::moved; using B::mode;
-    WideRay W;
+    typename WRaySel<ARITY>::type W;
     uint32_t cur;
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
@@ -1024,6 +1114,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
     }
     PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
+        PBRS_TP(0);
         uint32_t e = cur;
         if (e == PBRS_WREF_NONE) {
             if (!in_blas) {  // TLAS level: the next leaf that passed the scan (the reference's test: the extent never changes)
@@ -1047,18 +1138,36 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             hold_leaf(e);
             return;
         }
-        const WideTest t = wide_test(S.wnodes, e, C, W, t_max);
-        if (t.pass == 0u) {
-            if (sp == 0) mode = B::exit_mode();
-            return;
+        PBRS_TP(1);
+        if constexpr (ARITY == 2u) {
+            uint32_t first;
+            if (!pair_node(S, e, C, W, t_max, stk, sp, first)) {
+                mode = PBRS_WALK_SLOW;
+                return;
+            }
+            if (first == PBRS_WREF_NONE) {
+                PBRS_TP(2);
+                if (sp == 0) mode = B::exit_mode();
+            } else if (first & PBRS_WREF_LEAF) {
+                hold_leaf(first);
+            } else {
+                cur = first;
+            }
+        } else {
+            const WideTest t = wide_test(S.wnodes, e, C, W, t_max);
+            if (t.pass == 0u) {
+                PBRS_TP(2);
+                if (sp == 0) mode = B::exit_mode();
+                return;
+            }
+            if (sp + 3 > (int)S.wide_cap) {
+                mode = PBRS_WALK_SLOW;
+                return;
+            }
+            const uint32_t first = wide_push(wide_order_any(t, C.d), stk, sp);
+            if (first & PBRS_WREF_LEAF) hold_leaf(first);
+            else cur = first;
         }
-        if (sp + 3 > (int)S.wide_cap) {
-            mode = PBRS_WALK_SLOW;
-            return;
-        }
-        const uint32_t first = wide_push(wide_order_any(t, C.d), stk, sp);
-        if (first & PBRS_WREF_LEAF) hold_leaf(first);
-        else cur = first;
     }
     PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
         if (in_blas) {
@@ -1068,6 +1177,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             return;
         }
         mode = PBRS_WALK_NODE;
+        PBRS_TP(6);
         const pbrs_node leaf = load_node(S.nodes + S.flat_off + leaf_a);
         leaf_a = leaf.a;  // the instance
         inst_kind = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
@@ -1087,7 +1197,8 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             }
             if (space == PBRS_SPACE_TRANSLATED) inst_kind |= 0x100u;
             if (space == PBRS_SPACE_MOVED) W.set(C);
-            if (in.pad[1] == PBRS_WREF_NONE) {
+            const uint32_t wroot = wide_root_of<ARITY>(S, in, leaf_a);
+            if (wroot == PBRS_WREF_NONE) {
                 hold_leaf(in.blas_root);
                 return;
             }
@@ -1095,7 +1206,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
                 mode = B::exit_mode();
                 return;
             }
-            cur = in.pad[1];
+            cur = wroot;
         } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {
             leaf_a = in.blas_root;
             leaf_end = in.blas_root + 1u;
@@ -1104,9 +1215,11 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
     }
     PD void leaf_wave(const DevScene& S, Cnt<false>& cnt) {
         if (mode == PBRS_WALK_LEAF && leaf_end == PBRS_LEAF_UNVERIFIED) {  // the reference's test of the leaf's own box (intersect_bvh_pred, blas.rs:478-495)
+            PBRS_TP(3);
             const pbrs_node node = load_node(S.nodes + leaf_a);
             leaf_a = node.a;
             leaf_end = slab_rs(node, exact_space(C), t_max) ? node.a + (node.b & ~PBRS_LEAF_FLAG) : node.a;
+            if (leaf_end != leaf_a) PBRS_TP(4);
             if (leaf_end == leaf_a) mode = after_leaf();
         }
         const bool tri_leaf = mode == PBRS_WALK_LEAF;
@@ -1118,6 +1231,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
         const uint32_t hti = sh.from_owner(leaf_a) + sh.k();
         bool hit = false;
         if (sh.helper()) {
+            PBRS_TP(5);
             pbrs_tri_verts tv = load_tri(S.tv + hti);
             hit = mesh_tri_pred(tv, ho, hd, htmax);
         }

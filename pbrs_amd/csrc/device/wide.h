@@ -39,6 +39,9 @@ struct pbrs_wnode {
 #ifndef PBRS_WIDE_MIN_LEVELS
 #define PBRS_WIDE_MIN_LEVELS 4u  // scenes whose deepest BLAS has fewer wide levels keep the binary-walk kernels
 #endif
+#ifndef PBRS_PAIR_STACK_MAX
+#define PBRS_PAIR_STACK_MAX 24  // ... of the kernels that walk pair nodes: one entry per level at most
+#endif
 #define PBRS_WREF_LEAF 0x80000000u
 #define PBRS_WREF_NONE 0xffffffffu
 // slots 0, 1: the children of X's left child (or that child itself in slot 0, where it is a leaf); slots 2, 3: of its right child
@@ -129,4 +132,54 @@ PD uint32_t wide_push(const WideOrder& o, LaneStack stk, int& sp) {
     if (o.p[1] & o.p[0]) stk.put(sp + (int)(o.p[3] + o.p[2]), o.r[1]);
     sp += (int)(o.p[0] + o.p[1] + o.p[2] + o.p[3]) - 1;
     return o.p[0] ? o.r[0] : o.p[1] ? o.r[1] : o.p[2] ? o.r[2] : o.r[3];
+}
+
+// ---- pair nodes: the same argument taken ONE level at a time --------------------------------------------------------------------
+// A pair node holds the boxes of the two children of an inner node X of the reference's tree (left child in slot 0), tested
+// together with pn_slab_filter against the extent of that moment; the survivor the reference visits first (`ray.dir[axis] > 0`:
+// the left one) is taken next from a register, the other one pushed.  One dependent step per inner node that passes — the
+// binary walk takes one per box, pops of boxes that fail included — two filter tests in it instead of one exact test, 12 plane
+// coordinates and two links live instead of the 24 + 4 of a four-wide node (the closest-hit walk over those needs 117
+// registers: four waves per SIMD, where the binary walk has six).  Leaves come up unverified and get the reference's own test at
+// their turn, exactly as on the four-wide walk.
+struct pbrs_pnode {     // 64 bytes = half an L2 line
+    float lo[3][2];     // [axis][slot]: min planes   (bytes  0 .. 23)
+    float hi[3][2];     // [axis][slot]: max planes   (bytes 24 .. 47)
+    uint32_t child[2];  // PBRS_WREF_LEAF | index of the reference's leaf node in DevScene::nodes; else index of a pair node
+    uint32_t info;      // bits 0-1: split axis of X
+    uint32_t pad;
+};
+struct PairRay {
+    f3 r32;               // RN32 of the f64 reciprocals of the direction
+    uint32_t nx, ny, nz;  // byte offset of the planes met first on that axis within the node: axis * 8 (+ 24 where the direction is not positive)
+    PD void set(const RaySpace& C) {
+        r32 = mk3((float)C.rx, (float)C.ry, (float)C.rz);
+        nx = C.d.x > 0.0f ? 0u : 24u;
+        ny = C.d.y > 0.0f ? 8u : 32u;
+        nz = C.d.z > 0.0f ? 16u : 40u;
+    }
+    // `!(ray.dir[axis] > 0)`: the right child first (blas.rs:456-466)
+    PD bool right_first(uint32_t axis) const { return (axis == 0u ? nx : axis == 1u ? ny - 8u : nz - 16u) != 0u; }
+};
+struct PairTest {
+    uint32_t first, second;  // the children in the reference's visiting order
+    bool pf, ps;             // their boxes passed the filter
+};
+PD PairTest pair_test(const pbrs_wnode* nodes, uint32_t pi, const RaySpace& C, const PairRay& W, float t_max) {
+    const char* base = reinterpret_cast<const char*>(nodes);
+    const uint32_t at = pi * (uint32_t)sizeof(pbrs_pnode);
+    const float2 nx = *reinterpret_cast<const float2*>(base + (at + W.nx)), ny = *reinterpret_cast<const float2*>(base + (at + W.ny)),
+                 nz = *reinterpret_cast<const float2*>(base + (at + W.nz));
+    const float2 fx = *reinterpret_cast<const float2*>(base + (at + (24u - W.nx))), fy = *reinterpret_cast<const float2*>(base + (at + (40u - W.ny))),
+                 fz = *reinterpret_cast<const float2*>(base + (at + (56u - W.nz)));
+    const uint4 ch = *reinterpret_cast<const uint4*>(base + (at + 48u));
+    const bool p0 = pn_slab_filter(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, C.o.x, C.o.y, C.o.z, W.r32.x, W.r32.y, W.r32.z, t_max) != 0;
+    const bool p1 = pn_slab_filter(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, C.o.x, C.o.y, C.o.z, W.r32.x, W.r32.y, W.r32.z, t_max) != 0;
+    const bool swap = W.right_first(ch.z & 3u);
+    PairTest t;
+    t.first = swap ? ch.y : ch.x;
+    t.second = swap ? ch.x : ch.y;
+    t.pf = swap ? p1 : p0;
+    t.ps = swap ? p0 : p1;
+    return t;
 }

@@ -98,6 +98,10 @@ struct pbrs_ctx {
     // pass rendered with the path integrator: 0 = not yet, 1 = split, 2 = do not.  The image does not depend on it.
     int split_decision = 0;
     bool wide_extend = false, wide_shadow = false;  // the stage runs the walks over four-wide nodes (device/wide.h), the binary walks after it for what they refuse
+    bool pair_extend = false, pair_shadow = false;  // ... over pair nodes (device/wide.h) instead; wide_* is set as well
+    const pbrs_wnode* pnodes = nullptr;             // the pair nodes (kernels read them through DevScene::wnodes)
+    const uint32_t* proot = nullptr;                // per instance: the pair node of its mesh's root
+    uint32_t pair_cap = 0;                          // stack rows of the pair-node walks
     uint32_t* slow = nullptr;      // 2 * cap_slots: queue positions a wide-walk kernel handed to the binary-walk kernel
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
     bool sort_classes = true;      // PBRS_SORT_CLASSES=0 in the environment turns the class sort off (A/B timing)
@@ -213,7 +217,15 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
 
 // wide-walk kernels: DevScene::wide_cap stack rows, and for closest hit one row per scanned TLAS leaf (entry distances)
 size_t lds_bytes_wide(const pbrs_ctx* c, bool closest) {
-    return (size_t)(c->S.wide_cap + (closest ? c->S.n_flat : 0u)) * kBlock * sizeof(uint32_t);
+    const uint32_t cap = (closest ? c->pair_extend : c->pair_shadow) ? c->pair_cap : c->S.wide_cap;
+    return (size_t)(cap + (closest ? c->S.n_flat : 0u)) * kBlock * sizeof(uint32_t);
+}
+// the scene as a kernel that walks pair nodes sees it (kernels.h: the pair nodes travel in the wide nodes' fields)
+DevScene pair_view(const pbrs_ctx* c, DevScene S) {
+    S.wnodes = c->pnodes;
+    S.wide_cap = c->pair_cap;
+    S.wroot = c->proot;
+    return S;
 }
 size_t lds_bytes(const pbrs_ctx* c) {
     size_t b = (size_t)(c->stack_depth) * kBlock * sizeof(uint32_t);
@@ -283,6 +295,27 @@ uint32_t build_wide(const std::vector<pbrs_node>& nodes, uint32_t x, std::vector
     }
     w.info = info | used << 8;
     out[me] = w;
+    return me;
+}
+
+// Pair nodes over the binary subtree of inner node x (device/wide.h): the boxes of x's two children, the left one in slot 0.
+// Returns the index of x's pair node in `out`; `levels`: pair nodes on the longest way down.
+uint32_t build_pair(const std::vector<pbrs_node>& nodes, uint32_t x, std::vector<pbrs_pnode>& out, uint32_t level, uint32_t& levels) {
+    const uint32_t me = (uint32_t)out.size();
+    out.push_back(pbrs_pnode{});
+    levels = std::max(levels, level + 1u);
+    pbrs_pnode p{};
+    p.info = nodes[x].b & 3u;
+    const uint32_t child[2] = {x + 1u, nodes[x].a};
+    for (uint32_t s = 0; s < 2; ++s) {
+        const pbrs_node& n = nodes[child[s]];
+        for (int a = 0; a < 3; ++a) {
+            p.lo[a][s] = n.min[a];
+            p.hi[a][s] = n.max[a];
+        }
+        p.child[s] = (n.b & PBRS_LEAF_FLAG) ? (PBRS_WREF_LEAF | child[s]) : build_pair(nodes, child[s], out, level + 1u, levels);
+    }
+    out[me] = p;
     return me;
 }
 
@@ -378,6 +411,22 @@ void launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds
         return;
     }
     const uint32_t feat = (c->S.features & PBRS_FEAT_ALL) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u);
+    if (wide && c->pair_extend) {  // PBRS_FEAT_FLAT_TLAS is set (pbrs_upload_scene)
+        S = pair_view(c, S);
+#define W PBRS_FEAT_PAIR | PBRS_FEAT_FLAT_TLAS
+        switch (feat & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_LONG_WALKS)) {
+            case 0u: PBRS_LAUNCH_EXTEND(false, W); break;
+            case 1u: PBRS_LAUNCH_EXTEND(false, W | 1u); break;
+            case 2u: PBRS_LAUNCH_EXTEND(false, W | 2u); break;
+            case 3u: PBRS_LAUNCH_EXTEND(false, W | 3u); break;
+            case 8u: PBRS_LAUNCH_EXTEND(false, W | 8u); break;
+            case 9u: PBRS_LAUNCH_EXTEND(false, W | 9u); break;
+            case 10u: PBRS_LAUNCH_EXTEND(false, W | 10u); break;
+            default: PBRS_LAUNCH_EXTEND(false, W | 11u); break;
+        }
+#undef W
+        return;
+    }
 #ifdef PBRS_DEV_OVERRIDES  // the wide closest-hit walk is slower than the binary one (pbrs_upload_scene): developer builds only
     if (wide) {  // PBRS_FEAT_FLAT_TLAS is set (pbrs_upload_scene)
 #define W PBRS_FEAT_WIDE | PBRS_FEAT_FLAT_TLAS
@@ -419,11 +468,24 @@ void launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds
 }
 void launch_shadow(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds, const uint32_t* count, uint32_t* heads, const uint32_t* indirect,
                    uint32_t* slow_list, uint32_t* slow_count) {
+    DevScene S = c->S;
 #define PBRS_LAUNCH_SHADOW(ST, F) \
-    hipLaunchKernelGGL((k_shadow<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, count, heads, c->gcnt + 1, indirect, slow_list, slow_count)
+    hipLaunchKernelGGL((k_shadow<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, count, heads, c->gcnt + 1, indirect, slow_list, slow_count)
     // k_shadow never evaluates shading frames: PBRS_FEAT_SHADING_CHECK does not select it
     if (stats) {
         PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS);
+        return;
+    }
+    if (wide && c->pair_shadow) {
+        S = pair_view(c, S);
+#define W PBRS_FEAT_PAIR | PBRS_FEAT_FLAT_TLAS
+        switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
+            case 0u: PBRS_LAUNCH_SHADOW(false, W); break;
+            case 1u: PBRS_LAUNCH_SHADOW(false, W | 1u); break;
+            case 8u: PBRS_LAUNCH_SHADOW(false, W | 8u); break;
+            default: PBRS_LAUNCH_SHADOW(false, W | 9u); break;
+        }
+#undef W
         return;
     }
     if (wide) {
@@ -687,6 +749,9 @@ int configure_kernels(pbrs_ctx* c) {
         PBRS_K((k_extend<false, 20u>)), PBRS_K((k_extend<false, 21u>)), PBRS_K((k_extend<false, 22u>)), PBRS_K((k_extend<false, 23u>)),
         PBRS_K((k_extend<false, 28u>)), PBRS_K((k_extend<false, 29u>)), PBRS_K((k_extend<false, 30u>)), PBRS_K((k_extend<false, 31u>)),
 #endif
+        PBRS_K((k_extend<false, 36u>)), PBRS_K((k_extend<false, 37u>)), PBRS_K((k_extend<false, 38u>)), PBRS_K((k_extend<false, 39u>)),
+        PBRS_K((k_extend<false, 44u>)), PBRS_K((k_extend<false, 45u>)), PBRS_K((k_extend<false, 46u>)), PBRS_K((k_extend<false, 47u>)),
+        PBRS_K((k_shadow<false, 36u>)), PBRS_K((k_shadow<false, 37u>)), PBRS_K((k_shadow<false, 44u>)), PBRS_K((k_shadow<false, 45u>)),
         PBRS_K((k_shadow<false, 20u>)), PBRS_K((k_shadow<false, 21u>)), PBRS_K((k_shadow<false, 28u>)), PBRS_K((k_shadow<false, 29u>))};
 #undef PBRS_K
     for (const void* k : traversal_kernels) HIPCHK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -705,6 +770,16 @@ int pbrs_debug_shade_probe(unsigned long long* out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_shade_probe), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long zero[16] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_shade_probe), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef PBRS_PROBE_TRAV
+// developer probe: reads and clears the traversal loops' event counts ([0]: k_extend, [1]: k_shadow; kernels.h)
+int pbrs_debug_trav_probe(unsigned long long* out48) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_trav_probe), 48 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long zero[48] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trav_probe), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -970,6 +1045,26 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             S.wide_cap = std::max(4u, std::min(3u * levels + 1u, (uint32_t)PBRS_WIDE_STACK_MAX));
             wide_levels = levels;
         }
+        // Pair nodes over the same trees (device/wide.h): a walk pushes at most one entry per level above the deepest pair node
+        {
+            std::vector<pbrs_pnode> pairs;
+            std::vector<uint32_t> proot(inst.size(), PBRS_WREF_NONE);
+            std::map<uint32_t, uint32_t> pair_of_root;
+            uint32_t levels = 0;
+            for (size_t i = 0; i < inst.size(); ++i) {
+                const pbrs_instance& in = inst[i];
+                if (in.shape_kind != PBRS_SHAPE_MESH || (nodes[in.blas_root].b & PBRS_LEAF_FLAG)) continue;
+                auto it = pair_of_root.find(in.blas_root);
+                if (it == pair_of_root.end()) it = pair_of_root.emplace(in.blas_root, build_pair(nodes, in.blas_root, pairs, 0u, levels)).first;
+                proot[i] = it->second;
+            }
+            if (pairs.size() * sizeof(pbrs_pnode) >= (1ull << 32)) return fail(c, PBRS_E_LIMIT, "too many BVH nodes (pair nodes are addressed with 32-bit byte offsets)");
+            const pbrs_pnode* dev = nullptr;
+            if ((rc = upload(c, pairs.data(), pairs.size(), &dev))) return rc;
+            c->pnodes = reinterpret_cast<const pbrs_wnode*>(dev);
+            if ((rc = upload(c, proot.data(), proot.size(), &c->proot))) return rc;
+            c->pair_cap = std::max(2u, std::min(levels, (uint32_t)PBRS_PAIR_STACK_MAX));
+        }
         if ((rc = upload(c, inst.data(), inst.size(), &S.inst))) return rc;
     }
     if ((rc = upload(c, d->shapes, d->n_shapes, &S.shapes))) return rc;
@@ -1024,10 +1119,15 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     const bool wide_ok = S.fast_slab != 0u && wide_levels >= PBRS_WIDE_MIN_LEVELS;
     c->wide_extend = false;
     c->wide_shadow = c->shadow_flat && wide_ok;
+    c->pair_extend = c->pair_shadow = false;
 #ifdef PBRS_DEV_OVERRIDES
     if (const char* e = dev_env("PBRS_WIDE")) {  // developer override (A/B timing): bit 0 k_extend, bit 1 k_shadow
         c->wide_extend = flat_feature != 0u && wide_ok && (std::atoi(e) & 1);
         c->wide_shadow = c->wide_shadow && (std::atoi(e) & 2);
+    }
+    if (const char* e = dev_env("PBRS_PAIR")) {  // ... the walks over pair nodes instead: bit 0 k_extend, bit 1 k_shadow
+        if (flat_feature != 0u && wide_ok && (std::atoi(e) & 1)) c->wide_extend = c->pair_extend = true;
+        if (c->shadow_flat && wide_ok && (std::atoi(e) & 2)) c->wide_shadow = c->pair_shadow = true;
     }
 #endif
     for (uint32_t i = 0; i < d->n_instances; ++i) {
