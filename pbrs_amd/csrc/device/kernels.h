@@ -246,6 +246,12 @@ PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
 // C3 -1 %: the later steps run at few lanes) and keep one.
 #define PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS)                            \
     do {                                                                           \
+        if ((NSTEPS) == 0u && __ballot(walk.mode == PBRS_WALK_NODE)) { /* as long as most of the wave wants one: a loop of its own, whose registers the allocator serves first */ \
+            _Pragma("nounroll") do {                                               \
+                PBRS_KP_LANE(6, walk.mode == PBRS_WALK_NODE);                      \
+                if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);      \
+            } while ((uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_NODE)) >= PBRS_NODE_LOOP_MIN); \
+        }                                                                          \
         _Pragma("unroll") for (uint32_t k_ = 1; k_ < (NSTEPS); ++k_) {             \
             PBRS_KP_LANE(5 + (k_ < 2u ? k_ : 2u), walk.mode == PBRS_WALK_NODE);    \
             if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);          \
@@ -267,7 +273,7 @@ PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
         PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                                      \
         PBRS_KP_LANE(5, walk.mode == PBRS_WALK_NODE);                                                          \
         if (__ballot(walk.mode == PBRS_WALK_NODE)) PBRS_KP_WAVE(11);                                           \
-        if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                                          \
+        if ((NSTEPS) != 0u && walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                        \
         PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS);                                                              \
         const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                         \
         if (nl && (nl >= LEAF_MIN || __ballot(walk.mode == PBRS_WALK_NODE) == 0)) {                            \
@@ -422,6 +428,18 @@ PD void wave_append_slow(bool slow, uint32_t item, uint32_t* list, uint32_t* cou
 #ifndef PBRS_PAIR_NODE_STEPS
 #define PBRS_PAIR_NODE_STEPS 2u
 #endif
+#ifndef PBRS_CNODE_EXTEND_WAVES  // ... and for the kernels that walk compressed records
+#define PBRS_CNODE_EXTEND_WAVES 6
+#endif
+#ifndef PBRS_CNODE_SHADOW_WAVES
+#define PBRS_CNODE_SHADOW_WAVES 6
+#endif
+#ifndef PBRS_CNODE_NODE_STEPS
+#define PBRS_CNODE_NODE_STEPS 3u  // 0: node steps in a loop of their own while PBRS_NODE_LOOP_MIN lanes want one
+#endif
+#ifndef PBRS_NODE_LOOP_MIN
+#define PBRS_NODE_LOOP_MIN 36u
+#endif
 template <uint32_t ARITY, bool STATS, uint32_t FEAT>  // ARITY 0: the binary walks
 struct ClosestSel {
     typedef ClosestWalkW<FEAT, ARITY> type;
@@ -438,13 +456,14 @@ template <bool STATS, uint32_t FEAT>
 struct AnySel<0u, STATS, FEAT> {
     typedef AnyWalk<STATS, FEAT> type;
 };
-#define PBRS_WALK_ARITY(STATS, FEAT) ((STATS) ? 0u : ((FEAT) & PBRS_FEAT_PAIR) ? 2u : ((FEAT) & PBRS_FEAT_WIDE) ? 4u : 0u)
-#define PBRS_WALK_NSTEPS(FEAT, ARITY) (!((FEAT) & PBRS_FEAT_LONG_WALKS) ? 1u : (ARITY) == 2u ? PBRS_PAIR_NODE_STEPS : (ARITY) == 4u ? PBRS_WIDE_NODE_STEPS : PBRS_NODE_STEPS_LONG)
+#define PBRS_WALK_ARITY(STATS, FEAT) ((STATS) ? 0u : ((FEAT) & PBRS_FEAT_CNODE) ? 1u : ((FEAT) & PBRS_FEAT_PAIR) ? 2u : ((FEAT) & PBRS_FEAT_WIDE) ? 4u : 0u)
+#define PBRS_WALK_NSTEPS(FEAT, ARITY) \
+    (!((FEAT) & PBRS_FEAT_LONG_WALKS) ? 1u : (ARITY) == 1u ? PBRS_CNODE_NODE_STEPS : (ARITY) == 2u ? PBRS_PAIR_NODE_STEPS : (ARITY) == 4u ? PBRS_WIDE_NODE_STEPS : PBRS_NODE_STEPS_LONG)
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
 // handed a new ray at the next refill, the walks of the other lanes continue where they were.
 // `indirect` (binary-walk kernels working off a slow list): the queue positions to trace, `count` of them.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_PAIR) ? PBRS_PAIR_EXTEND_WAVES : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_EXTEND_WAVES : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES)
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PBRS_CNODE_EXTEND_WAVES : (FEAT & PBRS_FEAT_PAIR) ? PBRS_PAIR_EXTEND_WAVES : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_EXTEND_WAVES : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES)
     k_extend(DevScene S, PathState st, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect,
              uint32_t* slow_list, uint32_t* slow_count, uint32_t split) {
     extern __shared__ uint32_t lds_stack[];
@@ -1139,7 +1158,7 @@ __global__ void __launch_bounds__(256) k_class_scatter(PathState st, const uint3
 // ---- shadow ----------------------------------------------------------------------------------------------------
 // One work item per shadow ray (persistent, same refill scheme as k_extend); writes one occlusion byte.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_PAIR) ? PBRS_PAIR_SHADOW_WAVES : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_SHADOW_WAVES : PBRS_SHADOW_WAVES)
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PBRS_CNODE_SHADOW_WAVES : (FEAT & PBRS_FEAT_PAIR) ? PBRS_PAIR_SHADOW_WAVES : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_SHADOW_WAVES : PBRS_SHADOW_WAVES)
     k_shadow(DevScene S, PathState st, const uint32_t* count, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect, uint32_t* slow_list,
              uint32_t* slow_count) {
     extern __shared__ uint32_t lds_stack[];

@@ -850,6 +850,30 @@ template <>
 struct WRaySel<2u> {
     typedef PairRay type;
 };
+template <>
+struct WRaySel<1u> {  // the binary tree itself through its compressed records (wide.h): DevScene::cnodes, ::cframes
+    typedef CRay type;
+};
+// One node step on compressed records: node e against the extent; `next`: the child to take from the register (the other one is
+// pushed), PBRS_WREF_LEAF | e for a leaf whose record passed, PBRS_WREF_NONE for a record that failed; `false`: the push would not fit.
+PD bool cnode_step(const DevScene& S, uint32_t e, const RaySpace& C, const CRay& W, float ext, LaneStack stk, int& sp, uint32_t& next) {
+    const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[e];
+    const pbrs_cnode n{raw.x, raw.y, raw.z, raw.w};
+    next = PBRS_WREF_NONE;
+    if (!cnode_filter(n, W, ext)) return true;
+    if (n.link & PBRS_CNODE_LEAF) {
+        next = PBRS_WREF_LEAF | e;
+        return true;
+    }
+    if (sp + 1 > (int)S.wide_cap) return false;
+    // blas.rs:456-466: the left child first iff ray.dir[axis] > 0.  A = step * (1 / dir) carries the direction's sign (a zero step
+    // gives a signed zero), which keeps the direction itself out of the node step's registers.
+    const bool left_first = (__float_as_uint(comp(W.A, (int)((n.link >> 29) & 3u))) >> 31) == 0u;
+    const uint32_t left = e + 1u, right = n.link & PBRS_CNODE_CHILD_MASK;
+    stk.put(sp++, left_first ? right : left);
+    next = left_first ? left : right;
+    return true;
+}
 template <uint32_t ARITY>
 PD uint32_t wide_root_of(const DevScene& S, const pbrs_instance& in, uint32_t inst) {
     return ARITY == 2u ? S.wroot[inst] : in.pad[1];
@@ -879,17 +903,12 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         B::start(S, o, d, tmax, stk);
         cur = PBRS_WREF_NONE;
-        W.set(C);
+        if constexpr (ARITY != 1u) W.set(C);  // (compressed records: per mesh, at its boundary)
         if (mode != PBRS_WALK_SCAN) mode = PBRS_WALK_SLOW;  // not on the division-free test: the binary walk's ray
     }
     PD void scan_wave(const DevScene& S, LaneStack stk) {
         float* tl_block = reinterpret_cast<float*>(stk.base) - (threadIdx.x & (PBRS_TRAVERSAL_BLOCK - 1)) + S.wide_cap * PBRS_TRAVERSAL_BLOCK;
-#ifdef EXP_B
-        uint32_t tested_ = 0;
-        const uint32_t mine = FlatScan::run(S, mode == PBRS_WALK_SCAN, C, pn_inf(), tested_);
-#else
         const uint32_t mine = flat_scan_tlow(S, mode == PBRS_WALK_SCAN, C, tl_block);
-#endif
         if (mode == PBRS_WALK_SCAN) {
             cand = mine;
             mode = PBRS_WALK_NODE;
@@ -904,8 +923,55 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     // The f64 reciprocals are not state of a wide walk (exact_space): dropping them at the end of every loop round keeps six
     // registers from living across it (the shared scan reads them from every lane of the wave, fresh or not).
     PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
+    // The node step over compressed records, written for the instruction count of its common path (one load, one filter, selects):
+    // everything rare — the next scanned TLAS leaf, the end of a mesh — sits behind the one test for an empty stack.
+    PD void node_step_c(const DevScene& S, LaneStack stk) {
+        uint32_t e = cur;
+        if (e == PBRS_WREF_NONE) {
+            if (sp == 0) {  // (a wide walk is never below a TLAS entry: at the TLAS level the stack is empty)
+                if (in_blas) {
+                    mode = B::exit_mode();
+                } else if (cand == 0u) {
+                    mode = PBRS_WALK_DONE;
+                } else {  // the next scanned leaf whose box the reference's test passes NOW (t_low <= min(hi_el, t_max))
+                    const uint32_t k = (uint32_t)__builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    if (__uint_as_float(stk.get((int)(S.wide_cap + k))) <= t_max) {
+                        leaf_a = k;
+                        mode = PBRS_WALK_XFER;
+                    }
+                }
+                return;
+            }
+            e = stk.get(--sp);
+        }
+        PBRS_TP(1);
+        const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[e];
+        const bool pass = cnode_filter(pbrs_cnode{raw.x, raw.y, raw.z, raw.w}, W, lt);
+        const bool leaf = (raw.w & PBRS_CNODE_LEAF) != 0u;
+        const bool fits = sp < (int)S.wide_cap;
+        const bool inner = pass && !leaf && fits;
+        // blas.rs:456-466: the left child first iff ray.dir[axis] > 0; A = step * (1 / dir) carries the direction's sign (a zero
+        // step gives a signed zero), which keeps the direction itself out of this step's registers
+        const bool left_first = (__float_as_uint(comp(W.A, (int)((raw.w >> 29) & 3u))) >> 31) == 0u;
+        const uint32_t left = e + 1u, right = raw.w & PBRS_CNODE_CHILD_MASK;
+        if (inner) stk.put(sp, left_first ? right : left);
+        sp += inner ? 1 : 0;
+        cur = inner ? (left_first ? left : right) : PBRS_WREF_NONE;
+        lt = inner ? mt : lt;  // blas.rs:468: once a node has passed, the cloned ray's extent follows outer_hit (the root saw the incoming one)
+        if (pass && leaf) hold_leaf(e);
+        if (pass && !leaf && !fits) mode = PBRS_WALK_SLOW;  // the binary walk takes this ray from its start
+        if (!pass) {
+            PBRS_TP(2);
+            if (sp == 0) mode = B::exit_mode();
+        }
+    }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
         PBRS_TP(0);
+        if constexpr (ARITY == 1u) {
+            node_step_c(S, stk);
+            return;
+        }
         uint32_t e = cur;
         if (e == PBRS_WREF_NONE) {
             if (!in_blas) {  // TLAS level: the next scanned leaf whose box the reference's test passes NOW (t_low <= min(hi_el, t_max))
@@ -933,7 +999,22 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             return;
         }
         PBRS_TP(1);
-        if constexpr (ARITY == 2u) {
+        if constexpr (ARITY == 1u) {
+            uint32_t next;
+            if (!cnode_step(S, e, C, W, lt, stk, sp, next)) {
+                mode = PBRS_WALK_SLOW;
+                return;
+            }
+            if (next == PBRS_WREF_NONE) {
+                PBRS_TP(2);
+                if (sp == 0) mode = B::exit_mode();
+            } else if (next & PBRS_WREF_LEAF) {
+                hold_leaf(next);
+            } else {
+                cur = next;
+                lt = mt;  // blas.rs:468: after a node passed, the cloned ray's extent follows outer_hit (the root saw the incoming one)
+            }
+        } else if constexpr (ARITY == 2u) {
             uint32_t first;
             if (!pair_node(S, e, C, W, lt, stk, sp, first)) {
                 mode = PBRS_WALK_SLOW;
@@ -965,9 +1046,17 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     }
     PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
         if (in_blas) {
+            // the way out: Instance::intersect returns (bvh.rs:82-95) — ClosestWalk::xfer_step's first branch, restated here so that its
+            // second one (the way in, which this walk has its own version of below) is not compiled into this kernel twice: with both
+            // copies the allocator spilled some 40 registers around them
             const bool rebuilt = moved && !(inst_info & 0x40000000u);  // leave_instance rebuilds the world ray, reciprocals included
-            B::xfer_step(S, stk, cnt);  // the way out: Instance::intersect returns (bvh.rs:82-95)
-            if (rebuilt) W.set(C);
+            mode = PBRS_WALK_NODE;
+            in_blas = false;
+            leave_instance(S, stk, !moved ? PBRS_SPACE_WORLD : (inst_info & 0x40000000u) ? PBRS_SPACE_TRANSLATED : PBRS_SPACE_MOVED, C);
+            B::meet_best(cnt);
+            lt = t_max;  // back in the TLAS
+            if constexpr (ARITY != 1u)
+                if (rebuilt) W.set(C);
             return;
         }
         mode = PBRS_WALK_NODE;
@@ -993,7 +1082,13 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
                 return;
             }
             inst_info = kind | (in.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
-            if (space == PBRS_SPACE_MOVED) W.set(C);  // a new direction (make_space has just computed its reciprocals); else the world's stands
+            if constexpr (ARITY == 1u) {  // the ray on the grid of this mesh; the root's record is tested like any other, against the incoming extent
+                if (!W.set(C, S.cframes[cur_inst])) mode = PBRS_WALK_SLOW;  // too far from this mesh's grid: the binary walk's ray
+                cur = in.blas_root;
+                return;
+            }
+            if constexpr (ARITY != 1u)
+                if (space == PBRS_SPACE_MOVED) W.set(C);  // a new direction (make_space has just computed its reciprocals); else the world's stands
             const uint32_t wroot = wide_root_of<ARITY>(S, in, cur_inst);
             if (wroot == PBRS_WREF_NONE) {  // the mesh is one leaf: its box is tested, against the incoming extent, with its triangles
                 hold_leaf(in.blas_root);
@@ -1021,11 +1116,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             const pbrs_node node = load_node(S.nodes + leaf_a);
             leaf_a = node.a;
             leaf_end = node.a;
-#ifdef EXP_A
-            if (pn_slab_filter(node.min[0], node.min[1], node.min[2], node.max[0], node.max[1], node.max[2], C.o.x, C.o.y, C.o.z, W.r32.x, W.r32.y, W.r32.z, lt)) {
-#else
             if (slab_rs(node, exact_space(C), lt)) {
-#endif
                 PBRS_TP(4);
                 leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
                 if (leaf_end == leaf_a) lt = mt;  // an empty leaf still runs blas.rs:468
@@ -1099,7 +1190,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         B::start(S, o, d, tmax, stk);
         cur = PBRS_WREF_NONE;
-        W.set(C);
+        if constexpr (ARITY != 1u) W.set(C);
         if (mode != PBRS_WALK_SCAN) mode = PBRS_WALK_SLOW;
     }
     PD void scan_wave(const DevScene& S, LaneStack) {
@@ -1113,8 +1204,47 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
         mode = PBRS_WALK_LEAF;
     }
     PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
+    PD void node_step_c(const DevScene& S, LaneStack stk) {  // see ClosestWalkW::node_step_c
+        uint32_t e = cur;
+        if (e == PBRS_WREF_NONE) {
+            if (sp == 0) {
+                if (in_blas) {
+                    mode = B::exit_mode();
+                } else if (cand == 0u) {
+                    mode = PBRS_WALK_DONE;
+                } else {  // the next leaf that passed the scan (the reference's test: the extent never changes)
+                    leaf_a = (uint32_t)__builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    mode = PBRS_WALK_XFER;
+                }
+                return;
+            }
+            e = stk.get(--sp);
+        }
+        PBRS_TP(1);
+        const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[e];
+        const bool pass = cnode_filter(pbrs_cnode{raw.x, raw.y, raw.z, raw.w}, W, t_max);
+        const bool leaf = (raw.w & PBRS_CNODE_LEAF) != 0u;
+        const bool fits = sp < (int)S.wide_cap;
+        const bool inner = pass && !leaf && fits;
+        const bool left_first = (__float_as_uint(comp(W.A, (int)((raw.w >> 29) & 3u))) >> 31) == 0u;
+        const uint32_t left = e + 1u, right = raw.w & PBRS_CNODE_CHILD_MASK;
+        if (inner) stk.put(sp, left_first ? right : left);
+        sp += inner ? 1 : 0;
+        cur = inner ? (left_first ? left : right) : PBRS_WREF_NONE;
+        if (pass && leaf) hold_leaf(e);
+        if (pass && !leaf && !fits) mode = PBRS_WALK_SLOW;
+        if (!pass) {
+            PBRS_TP(2);
+            if (sp == 0) mode = B::exit_mode();
+        }
+    }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
         PBRS_TP(0);
+        if constexpr (ARITY == 1u) {
+            node_step_c(S, stk);
+            return;
+        }
         uint32_t e = cur;
         if (e == PBRS_WREF_NONE) {
             if (!in_blas) {  // TLAS level: the next leaf that passed the scan (the reference's test: the extent never changes)
@@ -1139,7 +1269,21 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             return;
         }
         PBRS_TP(1);
-        if constexpr (ARITY == 2u) {
+        if constexpr (ARITY == 1u) {
+            uint32_t next;
+            if (!cnode_step(S, e, C, W, t_max, stk, sp, next)) {
+                mode = PBRS_WALK_SLOW;
+                return;
+            }
+            if (next == PBRS_WREF_NONE) {
+                PBRS_TP(2);
+                if (sp == 0) mode = B::exit_mode();
+            } else if (next & PBRS_WREF_LEAF) {
+                hold_leaf(next);
+            } else {
+                cur = next;
+            }
+        } else if constexpr (ARITY == 2u) {
             uint32_t first;
             if (!pair_node(S, e, C, W, t_max, stk, sp, first)) {
                 mode = PBRS_WALK_SLOW;
@@ -1171,9 +1315,12 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
     }
     PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
         if (in_blas) {
-            const bool rebuilt = moved && !(inst_kind & 0x100u);
-            B::xfer_step(S, stk, cnt);
-            if (rebuilt) W.set(C);
+            const bool rebuilt = moved && !(inst_kind & 0x100u);  // (AnyWalk::xfer_step's first branch: see ClosestWalkW::xfer_step)
+            mode = PBRS_WALK_NODE;
+            in_blas = false;
+            leave_instance(S, stk, !moved ? PBRS_SPACE_WORLD : (inst_kind & 0x100u) ? PBRS_SPACE_TRANSLATED : PBRS_SPACE_MOVED, C);
+            if constexpr (ARITY != 1u)
+                if (rebuilt) W.set(C);
             return;
         }
         mode = PBRS_WALK_NODE;
@@ -1196,7 +1343,13 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
                 return;
             }
             if (space == PBRS_SPACE_TRANSLATED) inst_kind |= 0x100u;
-            if (space == PBRS_SPACE_MOVED) W.set(C);
+            if constexpr (ARITY == 1u) {
+                if (!W.set(C, S.cframes[leaf_a])) mode = PBRS_WALK_SLOW;
+                cur = in.blas_root;
+                return;
+            }
+            if constexpr (ARITY != 1u)
+                if (space == PBRS_SPACE_MOVED) W.set(C);
             const uint32_t wroot = wide_root_of<ARITY>(S, in, leaf_a);
             if (wroot == PBRS_WREF_NONE) {
                 hold_leaf(in.blas_root);

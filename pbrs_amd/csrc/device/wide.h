@@ -183,3 +183,55 @@ PD PairTest pair_test(const pbrs_wnode* nodes, uint32_t pi, const RaySpace& C, c
     t.ps = swap ? p0 : p1;
     return t;
 }
+
+// ---- compressed nodes: one 16-byte load per box --------------------------------------------------------------------------------
+// What bounds the traversal kernels is the CU's vector memory path as much as its vector ALUs: a load instruction whose 64 lanes
+// name 64 different lines costs the L1 one cycle per lane whatever its width (tools/microbench/gather_rates.hip), k_extend makes
+// 106 such accesses per ray on C4 (rocprofv3 TCP_TOTAL_CACHE_ACCESSES) — 0.89 per cycle and CU at full size, of a peak of 1 — and
+// a 32-byte node is two of them.  Since inner-node tests only prune (above), a walk may test a box that merely ENCLOSES the
+// node's: every BLAS node i gets a 16-byte record — its box on a 16-bit grid over its mesh, rounded outward, and its links —
+// fetched with ONE load and tested in grid coordinates with one multiply-add per plane.  A leaf whose record passes comes up
+// unverified, as on the wide walks, and the reference's own test reads the full node at the leaf's turn.
+//
+// Grid of a mesh (pbrs_upload_scene, build_cnodes): ONE step s for the three axes — the root box's longest side over 65532 —
+// and a base b one step below the root's min corner, so that every plane of the mesh lies between grid lines 1 and 65534.  A
+// record holds integers with  b + (q_lo + 1) s <= min plane  and  b + (q_hi - 1) s >= max plane  (real arithmetic; checked in
+// f64 at upload, where those sums are exact): the box on the grid, and ONE MORE STEP outward on every side.  That step pays for
+// every rounding on the way: for a ray (o, d) inside the guarded range, r = v_rcp_f32(d) (relative error <= 2^-22), CRay::set
+// computes A = RN(s r), B = RN(RN(b - o) r) per axis and the walk t' = RN(q A + B) — five roundings of relative size <= 2^-24
+// and r's, so  |t' - (b + q s - o) / d| <= 2^-21.5 (q |A| + |B|).  The reference's quotient RN(RN(p - o) / d) for the node's own
+// plane p is within 2^-23 (relative) of (p - o) / d.  A walk takes a ray onto the grid only while |B| <= 2^20 |A| on every axis
+// (its origin within 2^20 steps = 16 root boxes of the base: CRay::set's result; other rays go to the binary walk), where both
+// errors together stay below 2^-21 (2^16 + 2^20) |A| < 0.6 |A|, less than the extra step |A|.  Hence the quotient of the
+// record's plane lies on the outer side of the reference's quotient for the node's plane, on every axis, and with lo' =
+// max_axis min(t'), hi' = min_axis max(t') the reference's pass  max(lo_ref, 0) <= min(hi_ref, t_max)  implies
+// max(lo', 0) <= min(hi', t_max)  (min and max are monotone): cnode_filter never rejects a box the reference's test accepts.
+struct pbrs_cnode {
+    uint32_t x, y, z;  // q_lo | q_hi << 16 per axis
+    uint32_t link;     // bit 31: leaf; inner nodes: bits 29-30 the split axis, bits 0-28 the right child (the left one is i + 1)
+};
+#define PBRS_CNODE_LEAF 0x80000000u
+#define PBRS_CNODE_CHILD_MASK 0x1fffffffu
+#define PBRS_CNODE_RANGE 1048576.0f /* 2^20 grid steps */
+struct pbrs_cframe {  // the grid of an instance's mesh
+    float base[3], step;
+};
+struct CRay {
+    f3 A, B;
+    PD bool set(const RaySpace& C, const pbrs_cframe& f) {  // false: the ray's origin is too far from this grid
+        const f3 r = mk3(__builtin_amdgcn_rcpf(C.d.x), __builtin_amdgcn_rcpf(C.d.y), __builtin_amdgcn_rcpf(C.d.z));
+        A = mk3(f.step * r.x, f.step * r.y, f.step * r.z);
+        B = mk3((f.base[0] - C.o.x) * r.x, (f.base[1] - C.o.y) * r.y, (f.base[2] - C.o.z) * r.z);
+        return __builtin_fabsf(B.x) <= PBRS_CNODE_RANGE * __builtin_fabsf(A.x) && __builtin_fabsf(B.y) <= PBRS_CNODE_RANGE * __builtin_fabsf(A.y) &&
+               __builtin_fabsf(B.z) <= PBRS_CNODE_RANGE * __builtin_fabsf(A.z);
+    }
+};
+PD bool cnode_filter(const pbrs_cnode& n, const CRay& W, float t_max) {
+    // (explicit multiply-adds: contraction is off, and RN(q A) + B would be two roundings where the bound above counts one)
+    const float t0x = __builtin_fmaf((float)(n.x & 0xffffu), W.A.x, W.B.x), t1x = __builtin_fmaf((float)(n.x >> 16), W.A.x, W.B.x);
+    const float t0y = __builtin_fmaf((float)(n.y & 0xffffu), W.A.y, W.B.y), t1y = __builtin_fmaf((float)(n.y >> 16), W.A.y, W.B.y);
+    const float t0z = __builtin_fmaf((float)(n.z & 0xffffu), W.A.z, W.B.z), t1z = __builtin_fmaf((float)(n.z >> 16), W.A.z, W.B.z);
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+    return __builtin_fmaxf(lo, 0.0f) <= __builtin_fminf(hi, t_max);
+}

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -102,6 +103,8 @@ struct pbrs_ctx {
     const pbrs_wnode* pnodes = nullptr;             // the pair nodes (kernels read them through DevScene::wnodes)
     const uint32_t* proot = nullptr;                // per instance: the pair node of its mesh's root
     uint32_t pair_cap = 0;                          // stack rows of the pair-node walks
+    bool cnode_extend = false, cnode_shadow = false;  // ... over the binary tree's compressed records (device/wide.h); wide_* is set as well
+    uint32_t cnode_cap_x = 0, cnode_cap_s = 0;        // stack rows of those walks (k_extend, k_shadow): one entry per level, capped so that six blocks fit a CU
     uint32_t* slow = nullptr;      // 2 * cap_slots: queue positions a wide-walk kernel handed to the binary-walk kernel
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
     bool sort_classes = true;      // PBRS_SORT_CLASSES=0 in the environment turns the class sort off (A/B timing)
@@ -217,10 +220,14 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
 
 // wide-walk kernels: DevScene::wide_cap stack rows, and for closest hit one row per scanned TLAS leaf (entry distances)
 size_t lds_bytes_wide(const pbrs_ctx* c, bool closest) {
-    const uint32_t cap = (closest ? c->pair_extend : c->pair_shadow) ? c->pair_cap : c->S.wide_cap;
+    const uint32_t cap = (closest ? c->cnode_extend : c->cnode_shadow) ? (closest ? c->cnode_cap_x : c->cnode_cap_s) : (closest ? c->pair_extend : c->pair_shadow) ? c->pair_cap : c->S.wide_cap;
     return (size_t)(cap + (closest ? c->S.n_flat : 0u)) * kBlock * sizeof(uint32_t);
 }
 // the scene as a kernel that walks pair nodes sees it (kernels.h: the pair nodes travel in the wide nodes' fields)
+DevScene cnode_view(const pbrs_ctx* c, DevScene S, bool closest) {
+    S.wide_cap = closest ? c->cnode_cap_x : c->cnode_cap_s;
+    return S;
+}
 DevScene pair_view(const pbrs_ctx* c, DevScene S) {
     S.wnodes = c->pnodes;
     S.wide_cap = c->pair_cap;
@@ -296,6 +303,59 @@ uint32_t build_wide(const std::vector<pbrs_node>& nodes, uint32_t x, std::vector
     w.info = info | used << 8;
     out[me] = w;
     return me;
+}
+
+// Compressed records (device/wide.h) of the BLAS below `root` on the grid of that BLAS: one step for the three axes, the base one
+// step below the root's min corner, every plane rounded to the grid line on its outer side and moved one more step outward.  All
+// comparisons are made in f64, where b + q s is exact (24 + 17 + 24 bits).  False: the root box does not admit such a grid
+// (non-finite or absurdly large coordinates: the scene then keeps the walks over full nodes).
+bool build_cnodes(const std::vector<pbrs_node>& nodes, uint32_t root, std::vector<pbrs_cnode>& out, pbrs_cframe& frame) {
+    const pbrs_node& r = nodes[root];
+    double ext = 0.0;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, (double)r.max[a] - (double)r.min[a]);
+    if (!(ext >= 0.0) || !std::isfinite(ext)) return false;
+    float s = (float)(ext / 65532.0);
+    if (!(s > 0.0f)) s = 1e-30f;  // a mesh of one point
+    for (int tries = 0;; ++tries) {
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) {
+            float b = (float)((double)r.min[a] - (double)s);
+            while ((double)b + (double)s > (double)r.min[a]) b = std::nextafter(b, -INFINITY);  // grid line 1 at or below the min plane
+            frame.base[a] = b;
+            ok = ok && (double)b + 65534.0 * (double)s >= (double)r.max[a];                    // grid line 65534 at or above the max plane
+        }
+        if (ok) break;
+        if (tries > 64) return false;
+        s = std::nextafter(s, INFINITY);
+    }
+    frame.step = s;
+    std::vector<uint32_t> todo{root};
+    while (!todo.empty()) {
+        const uint32_t i = todo.back();
+        todo.pop_back();
+        const pbrs_node& n = nodes[i];
+        uint32_t q[3];
+        for (int a = 0; a < 3; ++a) {
+            const double b = frame.base[a], sd = s;
+            long lo = (long)std::floor(((double)n.min[a] - b) / sd), hi = (long)std::ceil(((double)n.max[a] - b) / sd);
+            lo = std::min(std::max(lo, 1l), 65534l);
+            hi = std::min(std::max(hi, 1l), 65534l);
+            while (lo > 1 && b + (double)lo * sd > (double)n.min[a]) --lo;
+            while (hi < 65534 && b + (double)hi * sd < (double)n.max[a]) ++hi;
+            if (b + (double)lo * sd > (double)n.min[a] || b + (double)hi * sd < (double)n.max[a]) return false;  // a node outside its root's box
+            q[a] = (uint32_t)(lo - 1) | (uint32_t)(hi + 1) << 16;
+        }
+        pbrs_cnode c{q[0], q[1], q[2], 0u};
+        if (n.b & PBRS_LEAF_FLAG) {
+            c.link = PBRS_CNODE_LEAF;
+        } else {
+            c.link = (n.b & 3u) << 29 | (n.a & PBRS_CNODE_CHILD_MASK);
+            todo.push_back(i + 1u);
+            todo.push_back(n.a);
+        }
+        out[i] = c;
+    }
+    return true;
 }
 
 // Pair nodes over the binary subtree of inner node x (device/wide.h): the boxes of x's two children, the left one in slot 0.
@@ -411,6 +471,24 @@ void launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds
         return;
     }
     const uint32_t feat = (c->S.features & PBRS_FEAT_ALL) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u);
+#ifdef PBRS_DEV_OVERRIDES  // the walks over compressed records, pair nodes and (closest hit) four-wide nodes lose against the binary walk
+                           // at six waves per SIMD: developer builds only
+    if (wide && c->cnode_extend) {  // PBRS_FEAT_FLAT_TLAS is set (pbrs_upload_scene)
+        S = cnode_view(c, S, true);
+#define W PBRS_FEAT_CNODE | PBRS_FEAT_FLAT_TLAS
+        switch (feat & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_LONG_WALKS)) {
+            case 0u: PBRS_LAUNCH_EXTEND(false, W); break;
+            case 1u: PBRS_LAUNCH_EXTEND(false, W | 1u); break;
+            case 2u: PBRS_LAUNCH_EXTEND(false, W | 2u); break;
+            case 3u: PBRS_LAUNCH_EXTEND(false, W | 3u); break;
+            case 8u: PBRS_LAUNCH_EXTEND(false, W | 8u); break;
+            case 9u: PBRS_LAUNCH_EXTEND(false, W | 9u); break;
+            case 10u: PBRS_LAUNCH_EXTEND(false, W | 10u); break;
+            default: PBRS_LAUNCH_EXTEND(false, W | 11u); break;
+        }
+#undef W
+        return;
+    }
     if (wide && c->pair_extend) {  // PBRS_FEAT_FLAT_TLAS is set (pbrs_upload_scene)
         S = pair_view(c, S);
 #define W PBRS_FEAT_PAIR | PBRS_FEAT_FLAT_TLAS
@@ -427,7 +505,6 @@ void launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds
 #undef W
         return;
     }
-#ifdef PBRS_DEV_OVERRIDES  // the wide closest-hit walk is slower than the binary one (pbrs_upload_scene): developer builds only
     if (wide) {  // PBRS_FEAT_FLAT_TLAS is set (pbrs_upload_scene)
 #define W PBRS_FEAT_WIDE | PBRS_FEAT_FLAT_TLAS
         switch (feat & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_LONG_WALKS)) {
@@ -476,6 +553,19 @@ void launch_shadow(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds
         PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS);
         return;
     }
+#ifdef PBRS_DEV_OVERRIDES
+    if (wide && c->cnode_shadow) {
+        S = cnode_view(c, S, false);
+#define W PBRS_FEAT_CNODE | PBRS_FEAT_FLAT_TLAS
+        switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
+            case 0u: PBRS_LAUNCH_SHADOW(false, W); break;
+            case 1u: PBRS_LAUNCH_SHADOW(false, W | 1u); break;
+            case 8u: PBRS_LAUNCH_SHADOW(false, W | 8u); break;
+            default: PBRS_LAUNCH_SHADOW(false, W | 9u); break;
+        }
+#undef W
+        return;
+    }
     if (wide && c->pair_shadow) {
         S = pair_view(c, S);
 #define W PBRS_FEAT_PAIR | PBRS_FEAT_FLAT_TLAS
@@ -488,6 +578,7 @@ void launch_shadow(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds
 #undef W
         return;
     }
+#endif
     if (wide) {
 #define W PBRS_FEAT_WIDE | PBRS_FEAT_FLAT_TLAS
         switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
@@ -749,9 +840,14 @@ int configure_kernels(pbrs_ctx* c) {
         PBRS_K((k_extend<false, 20u>)), PBRS_K((k_extend<false, 21u>)), PBRS_K((k_extend<false, 22u>)), PBRS_K((k_extend<false, 23u>)),
         PBRS_K((k_extend<false, 28u>)), PBRS_K((k_extend<false, 29u>)), PBRS_K((k_extend<false, 30u>)), PBRS_K((k_extend<false, 31u>)),
 #endif
+#ifdef PBRS_DEV_OVERRIDES
+        PBRS_K((k_extend<false, 68u>)), PBRS_K((k_extend<false, 69u>)), PBRS_K((k_extend<false, 70u>)), PBRS_K((k_extend<false, 71u>)),
+        PBRS_K((k_extend<false, 76u>)), PBRS_K((k_extend<false, 77u>)), PBRS_K((k_extend<false, 78u>)), PBRS_K((k_extend<false, 79u>)),
+        PBRS_K((k_shadow<false, 68u>)), PBRS_K((k_shadow<false, 69u>)), PBRS_K((k_shadow<false, 76u>)), PBRS_K((k_shadow<false, 77u>)),
         PBRS_K((k_extend<false, 36u>)), PBRS_K((k_extend<false, 37u>)), PBRS_K((k_extend<false, 38u>)), PBRS_K((k_extend<false, 39u>)),
         PBRS_K((k_extend<false, 44u>)), PBRS_K((k_extend<false, 45u>)), PBRS_K((k_extend<false, 46u>)), PBRS_K((k_extend<false, 47u>)),
         PBRS_K((k_shadow<false, 36u>)), PBRS_K((k_shadow<false, 37u>)), PBRS_K((k_shadow<false, 44u>)), PBRS_K((k_shadow<false, 45u>)),
+#endif
         PBRS_K((k_shadow<false, 20u>)), PBRS_K((k_shadow<false, 21u>)), PBRS_K((k_shadow<false, 28u>)), PBRS_K((k_shadow<false, 29u>))};
 #undef PBRS_K
     for (const void* k : traversal_kernels) HIPCHK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -969,6 +1065,8 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     DevScene S{};
     int rc;
     uint32_t wide_levels = 0;  // wide nodes on the longest way down a BLAS
+    bool cnodes_ok = false;    // every BLAS has its compressed records (device/wide.h; developer builds)
+    (void)cnodes_ok;
     {
         // DevScene::nodes: the TLAS, then its leaves alone in pre-order when the TLAS is small (the shared scan), then every
         // BLAS, in one array with absolute links — a walk reads nodes + index whatever tree it is in.
@@ -1045,6 +1143,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             S.wide_cap = std::max(4u, std::min(3u * levels + 1u, (uint32_t)PBRS_WIDE_STACK_MAX));
             wide_levels = levels;
         }
+#ifdef PBRS_DEV_OVERRIDES  // (developer builds: the shipped library runs neither walk and does not spend upload time and HBM on them)
         // Pair nodes over the same trees (device/wide.h): a walk pushes at most one entry per level above the deepest pair node
         {
             std::vector<pbrs_pnode> pairs;
@@ -1065,6 +1164,33 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             if ((rc = upload(c, proot.data(), proot.size(), &c->proot))) return rc;
             c->pair_cap = std::max(2u, std::min(levels, (uint32_t)PBRS_PAIR_STACK_MAX));
         }
+        // Compressed records of every BLAS a mesh instance enters (device/wide.h), on the grid of that BLAS's root
+        {
+            std::vector<pbrs_cnode> cn(nodes.size(), pbrs_cnode{0u, 0u, 0u, PBRS_CNODE_LEAF});
+            std::vector<pbrs_cframe> frames(inst.size(), pbrs_cframe{});
+            std::map<uint32_t, pbrs_cframe> frame_of_root;
+            cnodes_ok = nodes.size() <= PBRS_CNODE_CHILD_MASK;  // a record links with 29 bits
+            for (size_t i = 0; cnodes_ok && i < inst.size(); ++i) {
+                const pbrs_instance& in = inst[i];
+                if (in.shape_kind != PBRS_SHAPE_MESH) continue;
+                auto it = frame_of_root.find(in.blas_root);
+                if (it == frame_of_root.end()) {
+                    pbrs_cframe f{};
+                    cnodes_ok = build_cnodes(nodes, in.blas_root, cn, f) && cnodes_ok;
+                    it = frame_of_root.emplace(in.blas_root, f).first;
+                }
+                frames[i] = it->second;
+            }
+            if ((rc = upload(c, cn.data(), cn.size(), &S.cnodes))) return rc;
+            if ((rc = upload(c, frames.data(), frames.size(), &S.cframes))) return rc;
+            // A walk keeps the child it visits next in a register and pushes the other one: at most one entry per level.  Six blocks of
+            // a traversal kernel fit a CU's LDS with 26 rows each (k_extend: the entry distances of the scanned TLAS leaves take
+            // n_flat of them); the rare ray that wants more than the rest goes to the binary walk.
+            const uint32_t rows6 = (uint32_t)(kLdsBytesPerCU / 6 / (kBlock * sizeof(uint32_t)));
+            c->cnode_cap_s = std::max(2u, std::min(max_blas_height, rows6));
+            c->cnode_cap_x = std::max(2u, std::min(max_blas_height, std::max(rows6 - std::min(rows6, S.n_flat), 16u)));
+        }
+#endif
         if ((rc = upload(c, inst.data(), inst.size(), &S.inst))) return rc;
     }
     if ((rc = upload(c, d->shapes, d->n_shapes, &S.shapes))) return rc;
@@ -1120,10 +1246,15 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     c->wide_extend = false;
     c->wide_shadow = c->shadow_flat && wide_ok;
     c->pair_extend = c->pair_shadow = false;
+    c->cnode_extend = c->cnode_shadow = false;
 #ifdef PBRS_DEV_OVERRIDES
     if (const char* e = dev_env("PBRS_WIDE")) {  // developer override (A/B timing): bit 0 k_extend, bit 1 k_shadow
         c->wide_extend = flat_feature != 0u && wide_ok && (std::atoi(e) & 1);
         c->wide_shadow = c->wide_shadow && (std::atoi(e) & 2);
+    }
+    if (const char* e = dev_env("PBRS_CNODE")) {  // ... over the compressed records: bit 0 k_extend, bit 1 k_shadow
+        if (flat_feature != 0u && S.fast_slab != 0u && cnodes_ok && (std::atoi(e) & 1)) c->wide_extend = c->cnode_extend = true;
+        if (c->shadow_flat && S.fast_slab != 0u && cnodes_ok && (std::atoi(e) & 2)) c->wide_shadow = c->cnode_shadow = true;
     }
     if (const char* e = dev_env("PBRS_PAIR")) {  // ... the walks over pair nodes instead: bit 0 k_extend, bit 1 k_shadow
         if (flat_feature != 0u && wide_ok && (std::atoi(e) & 1)) c->wide_extend = c->pair_extend = true;
