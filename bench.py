@@ -304,16 +304,21 @@ class Workload:
                 "scene_bytes_per_launch": dom["scene_bytes_per_launch"], "cache_work_rate_GBps": dom["cache_work_rate_GBps"],
                 "ms_per_launch": dom["ms_per_launch"], "launches_per_step": dom["launches"],
                 "valu_issue_frac": dom.get("valu_issue_frac"), "valu_lanes_active": dom.get("valu_lanes_active"),
-                "note": "rank 0's kernels, the stage with the most time per frame; bound = valu_issue when the kernel fills a larger share of the "
-                        "chip's vector issue slots than of the HBM peak (frac stays the HBM fraction); achieved = (queue/state bytes that must "
+                "l1_access_frac": dom.get("l1_access_frac"), "l1_accesses_per_launch": dom.get("l1_accesses_per_launch"),
+                "ta_busy_share": dom.get("ta_busy_share"), "td_busy_share": dom.get("td_busy_share"),
+                "note": "rank 0's kernels, the stage with the most time per frame; bound = the resource the kernel fills the largest share of: "
+                        "hbm, valu_issue or l1_access (frac stays the HBM fraction); l1_access_frac = L1 accesses per launch (one per lane of "
+                        "a load whose lanes name different lines, whatever its width: rocprofv3 TCP_TOTAL_CACHE_ACCESSES, offline) over 256 CUs x "
+                        "one access per cycle x the live kernel time x 2.4 GHz; ta / td_busy_share = busy cycles of the texture address / data "
+                        "units over the kernel's cycles (offline); achieved = (queue/state bytes that must "
                         "cross HBM: record sizes of the kernels' layout x units of one launch, pbrs_amd/roofline.py, + scene bytes that missed the "
                         "caches) / HIP-event time per launch; frac_measured = traffic / time / peak; scene misses and traffic = L2 -> fabric bytes "
                         "per launch from separate rocprofv3 TCC passes (Infinity-Cache hits included: an upper bound of HBM bytes), measured "
                         "offline on the same sources (source hash checked), see profiles/; "
                         "cache_work_rate prices every node / triangle visit at record size and is NOT an HBM figure; valu_issue_frac = "
                         "share of the chip's vector issue slots the kernel fills (wave-level VALU instructions per launch from the SQ "
-                        "pass in profiles/, x 4 cycles, over 1024 SIMDs x the live kernel time x 2.4 GHz): where it is near 1 the kernel "
-                        "is bound by instruction issue, not by HBM",
+                        "pass in profiles/, x 4 cycles, over 1024 SIMDs x the live kernel time x 2.4 GHz): an upper bound — 32-bit-encoded f32 / "
+                        "integer instructions issue in 2.7 cycles, 64-bit encodings, f64 and conversions in about 4 (tools/microbench/issue_rates.hip)",
             },
             "traversal": trav,
             "stages_ms_per_step": times,

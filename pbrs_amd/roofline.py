@@ -41,7 +41,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 L2_BYTES_PER_XCD = 4 << 20
 N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs (same guide)
 CLOCK_HZ = 2.4e9        # peak engine clock (same guide); the sustained clock is lower, so issue fractions are lower bounds
-CYCLES_PER_WAVE_VALU = 4  # a wave64 vector instruction occupies its 16-lane SIMD for 4 cycles
+# Issue cost of a wave64 vector instruction (tools/microbench/issue_rates.hip, eight waves per SIMD, cycles at the clock
+# attribute): 2.7 for the 32-bit-encoded f32 / integer forms (v_mul_f32, v_sub_f32, v_min_f32 ...), 3.7-4.4 for the 64-bit
+# encodings (v_fma_f32, v_max3_f32, v_pk_*, DPP), every f64 operation and the f32 <-> f64 conversions, 8.6 for the
+# transcendentals.  The fraction below prices every instruction at 4: an UPPER bound of the share of issue slots a kernel fills
+# (rounds 1 and 2 took it for the exact figure); with the traversal kernels' mix it is about 0.8 of that.
+CYCLES_PER_WAVE_VALU = 4
+N_CU = 256
+L1_ACCESSES_PER_CU_CYCLE = 1.0  # a CU's L1 takes one access (one lane of a load whose lanes name different lines) per cycle,
+                                # whatever the load's width: tools/microbench/gather_rates.hip, 64.6 cycles per 64-lane load
 
 B_CLOSEST_RAY = 48    # two 16-byte ray vectors read + the 16-byte hit record written (PathState::q[.][0..1], ::hit)
 B_SHADOW_RAY = 44     # two 16-byte ray vectors read (::sr[0..1]) + a lone ray's outcome: 16 B read (::sr[2]), 12 B into L
@@ -114,6 +122,23 @@ def kernel_traffic(traffic_doc, kernel, stage_launches_per_frame=None):
     return total / n
 
 
+def kernel_field(traffic_doc, kernel, field, stage_launches_per_frame=None, per_launch=True):
+    """A per-launch counter (`per_launch`: summed over the launches of a stage launch, as kernel_traffic) or a share (mean
+    over the kernel's instantiations weighted by launches) of the uninstrumented instantiation(s) of `kernel`; None when absent."""
+    if not traffic_doc:
+        return None
+    rows = [v for k, v in traffic_doc.get("kernels", {}).items()
+            if (k == kernel or (k.startswith(kernel + "<") and not k.startswith(kernel + "<true"))) and field in v]
+    n = sum(v["launches"] for v in rows)
+    if not n:
+        return None
+    total = sum(v[field] * v["launches"] for v in rows)
+    if not per_launch:
+        return total / n
+    frames = traffic_doc.get("geometry", {}).get("frames")
+    return total / (frames * stage_launches_per_frame) if stage_launches_per_frame and frames else total / n
+
+
 def kernel_valu(traffic_doc, kernel, stage_launches_per_frame=None):
     """(wave-level vector instructions per stage launch, mean active lanes) of the uninstrumented instantiation(s) of
     `kernel` in a traffic document that carries the SQ pass (tools/traffic_from_pmc.py), or None."""
@@ -170,6 +195,16 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None):
             out[stage]["valu_insts_per_launch"] = valu[0]
             out[stage]["valu_lanes_active"] = valu[1]
             out[stage]["valu_issue_frac"] = valu[0] * CYCLES_PER_WAVE_VALU / (N_SIMD * sec * CLOCK_HZ)
+        l1 = kernel_field(traffic_doc, kernel, "l1_accesses", launches)
+        if l1 is not None and sec > 0:
+            # share of the L1s' access slots: a load whose 64 lanes name 64 lines is 64 accesses whatever its width, so a walk's
+            # node, triangle and record fetches count per lane — the other resource the traversal kernels fill
+            out[stage]["l1_accesses_per_launch"] = l1
+            out[stage]["l1_access_frac"] = l1 / (N_CU * L1_ACCESSES_PER_CU_CYCLE * sec * CLOCK_HZ)
+        for share in ("ta_busy_share", "td_busy_share"):
+            v = kernel_field(traffic_doc, kernel, share, per_launch=False)
+            if v is not None:
+                out[stage][share] = v
     return out
 
 
@@ -191,9 +226,10 @@ def traversal(report):
 
 
 def bound_of(stage_row):
-    """"valu_issue" when the kernel fills a larger share of the chip's vector issue slots than of the HBM peak, else "hbm"."""
-    v = stage_row.get("valu_issue_frac")
-    return "valu_issue" if (v is not None and v > stage_row["frac"]) else "hbm"
+    """The resource the kernel fills the largest share of: "hbm", "valu_issue" (the chip's vector issue slots, an upper bound)
+    or "l1_access" (the L1s' one access per cycle and CU)."""
+    cands = {"hbm": stage_row["frac"], "valu_issue": stage_row.get("valu_issue_frac") or 0.0, "l1_access": stage_row.get("l1_access_frac") or 0.0}
+    return max(cands.items(), key=lambda kv: kv[1])[0]
 
 
 def source_hash(root=None):

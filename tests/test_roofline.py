@@ -91,3 +91,18 @@ def test_source_hash_follows_the_kernel_sources(tmp_path):
     (tmp_path / "pbrs_amd" / "csrc" / "device" / "k.h").write_text("a ")
     assert roofline.source_hash(str(tmp_path)) != h0
     assert roofline.source_hash() == roofline.source_hash(os.path.dirname(os.path.dirname(os.path.abspath(roofline.__file__))))
+
+
+def test_l1_access_share_from_the_tcp_pass():
+    """The traversal kernels' other resource: a load whose 64 lanes name 64 lines is 64 L1 accesses whatever its width, and a
+    CU's L1 serves one per cycle (tools/microbench/gather_rates.hip).  Accesses per launch come from the offline TCP pass."""
+    doc = {"geometry": {"frames": 1}, "kernels": {"k_extend<false, 13u>": {"launches": 2, "l2_fabric_total": 4.0e6, "valu_insts": 1.0e5, "valu_lanes_active": 40.0,
+                                                                             "l1_accesses": 5.0e8, "td_busy_share": 0.8, "ta_busy_share": 0.6},
+                                                    "k_extend<true, 15u>": {"launches": 1, "l2_fabric_total": 1.0, "l1_accesses": 9e12}}}
+    rep = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30, traffic_doc=doc)
+    e = rep["extend"]
+    assert e["l1_accesses_per_launch"] == 5.0e8  # the instrumented variant is not the timed kernel
+    assert e["l1_access_frac"] == 5.0e8 / (256 * 1.0e-3 * 2.4e9)
+    assert e["td_busy_share"] == 0.8 and e["ta_busy_share"] == 0.6
+    assert roofline.bound_of(e) == "l1_access"
+    assert "l1_access_frac" not in rep["shadow"]

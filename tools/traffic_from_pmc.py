@@ -1,6 +1,6 @@
 """Turns rocprofv3 TCC counter passes (tools/pmc_summary.py outputs) into memory-side (L2 -> fabric) traffic per launch per kernel.
 
-    python tools/traffic_from_pmc.py GEOMETRY.json fetch.txt write.txt [rdreq_sizes.txt [wrreq.txt [sq_wave_cycles.txt]]]
+    python tools/traffic_from_pmc.py GEOMETRY.json fetch.txt write.txt [rdreq_sizes.txt [wrreq.txt [sq_wave_cycles.txt [tcp.txt [ta_td.txt]]]]]
 
 Units and gfx950 corrections as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are in
 KiB and come from the L2's memory-side request counters (Infinity-Cache hits are counted, not excluded); on gfx950
@@ -11,7 +11,9 @@ request-size counters of gfx950 (TCC_EA0_RDREQ_{32B,64B,128B}): read bytes = 32 
 of no recorded size counted at 64 B — reported as l2_fabric_read_by_request_size next to l2_fabric_read; bench.py uses the larger of
 the two so that a roofline fraction is never flattered.  The optional sixth file (the SQ pass) adds, per kernel, the vector
 instructions of a launch and the lanes active in them: what bench.py turns into the share of the chip's vector issue slots a
-kernel uses (a wave64 instruction occupies a 16-lane SIMD for 4 cycles) — the bound of the kernels HBM does not bind.
+kernel uses — one bound of the kernels HBM does not bind.  The optional seventh / eighth files (TCP and TA / TD passes) add the
+other one: the L1 accesses of a launch (one per lane and load instruction when the lanes name different lines: a CU's L1 serves
+one per cycle, tools/microbench/gather_rates.hip) and the busy cycles of the texture address / data units.
 """
 import json
 import re
@@ -36,6 +38,8 @@ fetch, write = parse(sys.argv[2]), parse(sys.argv[3])
 sizes = parse(sys.argv[4]) if len(sys.argv) > 4 else {}
 wr = parse(sys.argv[5]) if len(sys.argv) > 5 else {}
 sq = parse(sys.argv[6]) if len(sys.argv) > 6 else {}
+tcp = parse(sys.argv[7]) if len(sys.argv) > 7 else {}
+tatd = parse(sys.argv[8]) if len(sys.argv) > 8 else {}
 n_pixels = geo["pixels"]
 n_slots = n_pixels * geo["samples_per_pass"]
 res = {"unit": "bytes per launch", "geometry": geo, "source_hash": geo.get("source_hash"), "git_head": geo.get("git_head"),
@@ -71,6 +75,15 @@ for k in fetch:
         row["valu_lanes_active"] = q.get("SQ_THREAD_CYCLES_VALU", 0.0) / q["SQ_INSTS_VALU"]  # of 64
         if q.get("SQ_WAVE_CYCLES"):
             row["wave_wait_share"] = q.get("SQ_WAIT_INST_ANY", 0.0) / q["SQ_WAVE_CYCLES"]  # of a wave's cycles spent waiting on an instruction's operands
+    if k in tcp and tcp[k].get("TCP_TOTAL_CACHE_ACCESSES_sum") is not None:
+        q, dq = tcp[k], tcp[k]["dispatches"]
+        row["l1_accesses"] = q["TCP_TOTAL_CACHE_ACCESSES_sum"] / dq           # per launch, summed over the CUs
+        row["l1_miss_requests"] = q.get("TCP_TCC_READ_REQ_sum", 0.0) / dq       # read requests the L1s sent to the L2
+    if k in tatd and tatd[k].get("GRBM_GUI_ACTIVE"):
+        q = tatd[k]
+        # GRBM_GUI_ACTIVE sums the 8 XCDs; TA / TD busy cycles sum the 256 CUs
+        row["ta_busy_share"] = q.get("TA_TA_BUSY_sum", 0.0) / 256.0 / (q["GRBM_GUI_ACTIVE"] / 8.0)
+        row["td_busy_share"] = q.get("TD_TD_BUSY_sum", 0.0) / 256.0 / (q["GRBM_GUI_ACTIVE"] / 8.0)
     row["l2_fabric_total"] = rd + wb
     res["kernels"][k] = row
 print(json.dumps(res, indent=1))
