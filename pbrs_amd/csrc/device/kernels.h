@@ -181,6 +181,11 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #ifndef PBRS_SHADE_WAVES  // min waves per SIMD asked of the register allocator for k_shade (2nd arg of __launch_bounds__)
 #define PBRS_SHADE_WAVES 3
 #endif
+#ifndef PBRS_FOURIER_SHADE_WAVES  // ... and for its variants that carry the Fourier lobe (device/fourier.h).  At three waves they keep 168
+#define PBRS_FOURIER_SHADE_WAVES 3  // registers and 428 bytes of scratch per lane, at two 255 registers and none — and are SLOWER: a 960 x 640,
+#endif                              // 64-spp frame of tests/fourier_scenes.py shades in 124 / 228 ms at three and 147 / 285 ms at two
+                                    // (tools/fourier_bench.py).  The spill code sits outside the series loops (one reload in 7 300
+                                    // instructions at loop depth 2); what the lobe costs is the recomputed series itself.
 
 // One round of the traversal loop ("if-if"): lanes in the node state take a node step, then the wave tests the primitives
 // of its held leaves (leaf_wave: triangle tests shared out over all 64 lanes), so lanes in different phases of their walks
@@ -581,7 +586,7 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 //                             kernels with this bit contain (its f64 series sums and Newton loops are long and register-hungry)
 #define PBRS_SHADE_FOURIER 8u
 template <uint32_t INTEG, bool TEX, uint32_t SPEC>
-__global__ void __launch_bounds__(256, PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
+__global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
                                               uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count, uint32_t sorted, const uint2* range) {
     // per-hit lobe lists of textured materials (Bsdf::hit_lobe / hit_albedo); absent from the untextured instantiation
     __shared__ uint32_t s_hit_lobe[TEX ? PBRS_MAX_BXDFS * 256 : 1];
