@@ -451,7 +451,7 @@ struct ClosestSel {
 };
 template <bool STATS, uint32_t FEAT>
 struct ClosestSel<0u, STATS, FEAT> {
-    typedef ClosestWalk<STATS, FEAT> type;
+    typedef ClosestWalk<STATS, (FEAT & PBRS_FEAT_ALL), !STATS && (FEAT & PBRS_FEAT_GRID) != 0u> type;
 };
 template <uint32_t ARITY, bool STATS, uint32_t FEAT>
 struct AnySel {
@@ -459,7 +459,7 @@ struct AnySel {
 };
 template <bool STATS, uint32_t FEAT>
 struct AnySel<0u, STATS, FEAT> {
-    typedef AnyWalk<STATS, FEAT> type;
+    typedef AnyWalk<STATS, (FEAT & PBRS_FEAT_ALL), !STATS && (FEAT & PBRS_FEAT_GRID) != 0u> type;
 };
 #define PBRS_WALK_ARITY(STATS, FEAT) ((STATS) ? 0u : ((FEAT) & PBRS_FEAT_CNODE) ? 1u : ((FEAT) & PBRS_FEAT_PAIR) ? 2u : ((FEAT) & PBRS_FEAT_WIDE) ? 4u : 0u)
 #define PBRS_WALK_NSTEPS(FEAT, ARITY) \
@@ -481,7 +481,8 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
-    typename ClosestSel<ARITY, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
+    typename ClosestSel<ARITY, STATS, (ARITY ? (FEAT & PBRS_FEAT_ALL) : (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_GRID)))>::type walk;
+    constexpr bool GRID = !STATS && ARITY == 0u && (FEAT & PBRS_FEAT_GRID) != 0u;
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
     uint32_t item = 0;  // queue position of the lane's ray
@@ -534,6 +535,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
                 }
                 if constexpr (WIDE) walk.scan_wave(S, stk);
                 else walk.scan_wave(S, cnt);
+                if constexpr (GRID) walk.forget_reciprocals();  // the scan was their last reader (exact_space recomputes them)
                 live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
             if (live == 0) {
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
             }
         }
         PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY));
-        if constexpr (WIDE) walk.forget_reciprocals();
+        if constexpr (WIDE || GRID) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
     if (!STATS) PBRS_KP_FLUSH(0, walk);
@@ -1174,7 +1176,8 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
-    typename AnySel<ARITY, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
+    typename AnySel<ARITY, STATS, (ARITY ? (FEAT & PBRS_FEAT_ALL) : (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_GRID)))>::type walk;
+    constexpr bool GRID = !STATS && ARITY == 0u && (FEAT & PBRS_FEAT_GRID) != 0u;
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
     uint32_t item = 0, rec = 0;
@@ -1218,6 +1221,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
                 }
                 if constexpr (WIDE) walk.scan_wave(S, stk);
                 else walk.scan_wave(S, cnt);
+                if constexpr (GRID) walk.forget_reciprocals();  // the scan was their last reader (exact_space recomputes them)
                 live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
             if (live == 0) {
@@ -1229,7 +1233,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
             }
         }
         PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY));
-        if constexpr (WIDE) walk.forget_reciprocals();
+        if constexpr (WIDE || GRID) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, 0u);
     if (!STATS) PBRS_KP_FLUSH(1, walk);

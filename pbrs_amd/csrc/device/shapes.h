@@ -79,6 +79,7 @@ struct DevScene {
 #define PBRS_FEAT_LONG_WALKS 8u     // kernels only (not a property of the walks): several node steps per loop round (kernels.h)
 #define PBRS_FEAT_WIDE 16u          // kernels only: the walks over four-wide nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
 #define PBRS_FEAT_PAIR 32u          // kernels only: the same walks over pair nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
+#define PBRS_FEAT_GRID 128u         // kernels only: the BINARY walks with a mesh's box tests made on the compressed records (traverse.h, GRID); scanned TLAS only
 #define PBRS_FEAT_CNODE 64u         // kernels only: the same walks over the binary tree's compressed records (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
 #define PBRS_FLAT_TLAS_MIN 2u
 // Largest TLAS the wave scans instead of walking (tools/tlas_probe.py, C5's scene family at 960x540, ms per 64 spp, walk vs

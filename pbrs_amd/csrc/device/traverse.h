@@ -332,7 +332,21 @@ PD uint32_t flat_scan_tlow(const DevScene& S, bool fresh, const RaySpace& R, flo
     return mine;
 }
 
-template <bool STATS, uint32_t FEAT>
+// GRID walks: the binary walks below with the box tests of a mesh's nodes made on the nodes' compressed records (wide.h: one
+// 16-byte load and a filter instead of two loads and the exact test) for rays on the division-free test.  A leaf whose record
+// passes is held unverified until the shared leaf step gives it the reference's own test; the box of a scanned TLAS leaf is
+// tested, exactly, at the boundary step that would enter it; the f64 reciprocals are recomputed for those few exact tests
+// (exact_space) instead of living in six registers.  Only for scenes whose TLAS is scanned (DevScene::n_flat != 0).
+template <bool GRID>
+struct GridSel {
+    struct type {};
+};
+template <>
+struct GridSel<true> {
+    typedef CRay type;
+};
+#define PBRS_BOX_PENDING 0x80000000u  // ClosestWalk::cur_inst of a GRID walk at a boundary: bits 0-30 name a scanned TLAS leaf whose box is still to be tested
+template <bool STATS, uint32_t FEAT, bool GRID = false>
 struct ClosestWalk {
     RaySpace C;  // the space the lane is walking in (the world ray in the TLAS, the instance's ray below a TLAS leaf): one
                  // box-test call serves lanes in either tree.  The world ray is read again on the way out (reload_world).
@@ -346,7 +360,9 @@ struct ClosestWalk {
     uint32_t cand;        // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, moved;  // moved: C is not the world ray (inst_info bit 30: only its origin differs)
     uint32_t mode;
+    typename GridSel<GRID>::type G;  // GRID walks: the ray on the grid of the mesh it is in
     PBRS_TP_FIELDS
+    PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }  // GRID walks: not state (exact_space recomputes them)
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         C = make_space(o, d, S.fast_slab != 0);
@@ -394,6 +410,42 @@ struct ClosestWalk {
         if (in_blas && sp == blas_base) {  // the instance's entries are used up: leave it (xfer_step, or finish at retire time)
             mode = exit_mode();
             return;
+        }
+        if constexpr (GRID) {
+            if (sp == 0) {  // the next scanned TLAS leaf: its box gets the reference's test of this moment at the boundary step
+                if (cand == 0u) {
+                    mode = PBRS_WALK_DONE;
+                    return;
+                }
+                cur_inst = PBRS_BOX_PENDING | (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1u;
+                mode = PBRS_WALK_XFER;
+                return;
+            }
+            if (in_blas && C.fast) {  // a mesh's node through its compressed record
+                const uint32_t ni = stk.get(--sp);
+                PBRS_TP(1);
+                const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[ni];
+                if (!cnode_filter(pbrs_cnode{raw.x, raw.y, raw.z, raw.w}, G, lt)) {
+                    PBRS_TP(2);
+                    if (PBRS_EARLY_OUT && sp == blas_base) mode = exit_mode();
+                    return;
+                }
+                if (!(raw.w & PBRS_CNODE_LEAF)) {
+                    // blas.rs:456-466: the left child first iff ray.dir[axis] > 0 — the sign A = step * (1 / dir) carries
+                    const bool left_first = (__float_as_uint(comp(G.A, (int)((raw.w >> 29) & 3u))) >> 31) == 0u;
+                    const uint32_t left = ni + 1u, right = raw.w & PBRS_CNODE_CHILD_MASK;
+                    stk.put(sp++, left_first ? right : left);
+                    stk.put(sp++, left_first ? left : right);
+                    lt = mt;  // blas.rs:468
+                } else {
+                    PBRS_TP(3);
+                    leaf_a = ni;  // held unverified: leaf_wave gives it the reference's own test, with the extent of that moment
+                    leaf_end = 0xffffffffu;
+                    mode = PBRS_WALK_LEAF;
+                }
+                return;
+            }
         }
         // One box test serves lanes at a BLAS / TLAS node and lanes whose turn it is to test a scanned leaf of a small TLAS
         // — the test the reference makes at this moment (scan_wave only filters).
@@ -488,6 +540,14 @@ struct ClosestWalk {
         // walk is back at this stack level.  A mesh continues in the node state with its BLAS root, an IsolatedTriangle
         // is one held triangle record; either way the candidate (mt, ...) meets `best` at the exit above (or at retire
         // time, finish).  An analytic shape is visited here and now (analytic_visit).
+        if constexpr (GRID) {
+            if (cur_inst & PBRS_BOX_PENDING) {  // a scanned TLAS leaf at its turn: the reference's box test, with the extent of this moment
+                const pbrs_node leaf = load_node(S.nodes + S.flat_off + (cur_inst & ~PBRS_BOX_PENDING));
+                if (!slab_rs(leaf, exact_space(C), lt)) return;  // (mode is NODE again: the next scanned leaf)
+                cur_inst = leaf.a;
+                inst_info = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+            }
+        }
         const pbrs_instance& in = S.inst[cur_inst];
         CNT(instances);
         PBRS_TP(6);
@@ -505,6 +565,11 @@ struct ClosestWalk {
         if (kind == PBRS_SHAPE_MESH) {
             inst_info = kind | (in.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
             stk.put(sp++, in.blas_root);
+            if constexpr (GRID) {
+                // onto the grid of this mesh; a ray too far from it walks the mesh's full nodes with the literal divisions (always
+                // the reference's test; it stays on them until a boundary step rebuilds its space)
+                if (C.fast && !G.set(C, S.cframes[cur_inst])) C.fast = false;
+            }
         } else if (kind == PBRS_SHAPE_TRIANGLE) {
             // IsolatedTriangle (simple.rs:417-426): one triangle record, no boxes, no shading frame
             inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
@@ -562,6 +627,19 @@ struct ClosestWalk {
 
     // The held leaves of the whole wave in one execution (TriShare); every lane of the wave calls this together.
     PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
+        if constexpr (GRID) {
+            if (mode == PBRS_WALK_LEAF && leaf_end == 0xffffffffu) {  // a leaf whose record passed: the reference's test of its own box
+                const pbrs_node node = load_node(S.nodes + leaf_a);
+                leaf_a = node.a;
+                leaf_end = node.a;
+                if (slab_rs(node, exact_space(C), lt)) {
+                    PBRS_TP(4);
+                    leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
+                    if (leaf_end == leaf_a) lt = mt;  // an empty leaf still runs blas.rs:468
+                }
+                if (leaf_end == leaf_a) mode = sp == blas_base ? exit_mode() : PBRS_WALK_NODE;
+            }
+        }
         const bool tri_leaf = mode == PBRS_WALK_LEAF;  // analytic shapes never wait here (analytic_visit)
         TriShare sh;
         sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
@@ -633,7 +711,7 @@ struct ClosestWalk {
 // the visiting order cannot change the answer and nothing is carried between instances, so BLAS children
 // are visited near-first (by the sign of the ray direction on the split axis), which reaches an occluder
 // sooner than the reference's left-first recursion.
-template <bool STATS, uint32_t FEAT>
+template <bool STATS, uint32_t FEAT, bool GRID = false>  // GRID: see ClosestWalk
 struct AnyWalk {
     RaySpace C;
     float t_max;
@@ -642,7 +720,9 @@ struct AnyWalk {
     uint32_t cand;  // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, occluded, moved;  // moved: C is not the world ray (inst_kind bit 8: only its origin differs)
     uint32_t mode;
+    typename GridSel<GRID>::type G;
     PBRS_TP_FIELDS
+    PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         C = make_space(o, d, S.fast_slab != 0);
@@ -699,6 +779,29 @@ struct AnyWalk {
             return;
         }
         const uint32_t ni = stk.get(--sp);
+        if constexpr (GRID) {
+            if (in_blas && C.fast) {  // a mesh's node through its compressed record (ClosestWalk::node_step)
+                PBRS_TP(1);
+                const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[ni];
+                if (!cnode_filter(pbrs_cnode{raw.x, raw.y, raw.z, raw.w}, G, t_max)) {
+                    PBRS_TP(2);
+                    if (PBRS_EARLY_OUT && sp == blas_base) mode = exit_mode();
+                    return;
+                }
+                if (!(raw.w & PBRS_CNODE_LEAF)) {
+                    const bool left_first = (__float_as_uint(comp(G.A, (int)((raw.w >> 29) & 3u))) >> 31) == 0u;
+                    const uint32_t left = ni + 1u, right = raw.w & PBRS_CNODE_CHILD_MASK;
+                    stk.put(sp++, left_first ? right : left);
+                    stk.put(sp++, left_first ? left : right);
+                } else {
+                    PBRS_TP(3);
+                    leaf_a = ni;
+                    leaf_end = 0xffffffffu;
+                    mode = PBRS_WALK_LEAF;
+                }
+                return;
+            }
+        }
         const pbrs_node node = load_node(S.nodes + ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
@@ -750,6 +853,9 @@ struct AnyWalk {
         if (inst_kind == PBRS_SHAPE_MESH) {
             if (space == PBRS_SPACE_TRANSLATED) inst_kind |= 0x100u;  // only meshes: the tests below read the kind before or mask it
             stk.put(sp++, in.blas_root);
+            if constexpr (GRID) {
+                if (C.fast && !G.set(C, S.cframes[leaf_a])) C.fast = false;  // (ClosestWalk::xfer_step)
+            }
         } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {  // IsolatedTriangle::occludes (simple.rs:428-433): its triangle record
             leaf_a = in.blas_root;
             leaf_end = in.blas_root + 1u;
@@ -759,6 +865,15 @@ struct AnyWalk {
     // The held leaves of the whole wave in one execution (TriShare); every lane of the wave calls this together.
     // `intersect_bvh_pred` stops at a leaf's first occluder (blas.rs:478-495): the owner counts its triangles up to that one.
     PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
+        if constexpr (GRID) {
+            if (mode == PBRS_WALK_LEAF && leaf_end == 0xffffffffu) {  // the reference's test of the leaf's own box (intersect_bvh_pred, blas.rs:478-495)
+                const pbrs_node node = load_node(S.nodes + leaf_a);
+                leaf_a = node.a;
+                leaf_end = slab_rs(node, exact_space(C), t_max) ? node.a + (node.b & ~PBRS_LEAF_FLAG) : node.a;
+                if (leaf_end != leaf_a) PBRS_TP(4);
+                if (leaf_end == leaf_a) mode = sp == blas_base ? exit_mode() : PBRS_WALK_NODE;
+            }
+        }
         const bool tri_leaf = mode == PBRS_WALK_LEAF;  // analytic shapes never wait here (analytic_visit)
         TriShare sh;
         sh.build(tri_leaf ? leaf_end - leaf_a : 0u);

@@ -103,6 +103,7 @@ struct pbrs_ctx {
     const pbrs_wnode* pnodes = nullptr;             // the pair nodes (kernels read them through DevScene::wnodes)
     const uint32_t* proot = nullptr;                // per instance: the pair node of its mesh's root
     uint32_t pair_cap = 0;                          // stack rows of the pair-node walks
+    bool grid_extend = false, grid_shadow = false;    // the stage's binary walk tests a mesh's boxes on the compressed records (traverse.h, GRID walks)
     bool cnode_extend = false, cnode_shadow = false;  // ... over the binary tree's compressed records (device/wide.h); wide_* is set as well
     uint32_t cnode_cap_x = 0, cnode_cap_s = 0;        // stack rows of those walks (k_extend, k_shadow): one entry per level, capped so that six blocks fit a CU
     uint32_t* slow = nullptr;      // 2 * cap_slots: queue positions a wide-walk kernel handed to the binary-walk kernel
@@ -523,6 +524,23 @@ void launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds
 #else
     (void)wide;
 #endif
+#ifdef PBRS_DEV_OVERRIDES  // (measured: with 37 % fewer L1 accesses per ray and the same six waves per SIMD, 4 % slower on C4, 30 % on C2 / C3: DESIGN.md)
+    if (c->grid_extend && (feat & PBRS_FEAT_FLAT_TLAS) && S.n_flat != 0u) {
+#define G PBRS_FEAT_GRID | PBRS_FEAT_FLAT_TLAS
+        switch (feat & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_LONG_WALKS)) {
+            case 0u: PBRS_LAUNCH_EXTEND(false, G); break;
+            case 1u: PBRS_LAUNCH_EXTEND(false, G | 1u); break;
+            case 2u: PBRS_LAUNCH_EXTEND(false, G | 2u); break;
+            case 3u: PBRS_LAUNCH_EXTEND(false, G | 3u); break;
+            case 8u: PBRS_LAUNCH_EXTEND(false, G | 8u); break;
+            case 9u: PBRS_LAUNCH_EXTEND(false, G | 9u); break;
+            case 10u: PBRS_LAUNCH_EXTEND(false, G | 10u); break;
+            default: PBRS_LAUNCH_EXTEND(false, G | 11u); break;
+        }
+#undef G
+        return;
+    }
+#endif
     switch (feat) {
         case 0u: PBRS_LAUNCH_EXTEND(false, 0u); break;
         case 1u: PBRS_LAUNCH_EXTEND(false, 1u); break;
@@ -590,6 +608,19 @@ void launch_shadow(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds
 #undef W
         return;
     }
+#ifdef PBRS_DEV_OVERRIDES
+    if (c->grid_shadow && c->shadow_flat && S.n_flat != 0u) {
+#define G PBRS_FEAT_GRID | PBRS_FEAT_FLAT_TLAS
+        switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
+            case 0u: PBRS_LAUNCH_SHADOW(false, G); break;
+            case 1u: PBRS_LAUNCH_SHADOW(false, G | 1u); break;
+            case 8u: PBRS_LAUNCH_SHADOW(false, G | 8u); break;
+            default: PBRS_LAUNCH_SHADOW(false, G | 9u); break;
+        }
+#undef G
+        return;
+    }
+#endif
     switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->shadow_flat ? PBRS_FEAT_FLAT_TLAS : 0u) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
         case 0u: PBRS_LAUNCH_SHADOW(false, 0u); break;
         case PBRS_FEAT_ANALYTIC: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC); break;
@@ -836,6 +867,11 @@ int configure_kernels(pbrs_ctx* c) {
         PBRS_K((k_shadow<false, 0u>)), PBRS_K((k_shadow<false, 1u>)), PBRS_K((k_shadow<false, 4u>)), PBRS_K((k_shadow<false, 5u>)),
         PBRS_K((k_shadow<false, 8u>)), PBRS_K((k_shadow<false, 9u>)), PBRS_K((k_shadow<false, 12u>)), PBRS_K((k_shadow<false, 13u>)),
         PBRS_K((k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>)), PBRS_K(k_intersect_rays<false>), PBRS_K(k_intersect_rays<true>),
+#ifdef PBRS_DEV_OVERRIDES
+        PBRS_K((k_extend<false, 132u>)), PBRS_K((k_extend<false, 133u>)), PBRS_K((k_extend<false, 134u>)), PBRS_K((k_extend<false, 135u>)),
+        PBRS_K((k_extend<false, 140u>)), PBRS_K((k_extend<false, 141u>)), PBRS_K((k_extend<false, 142u>)), PBRS_K((k_extend<false, 143u>)),
+        PBRS_K((k_shadow<false, 132u>)), PBRS_K((k_shadow<false, 133u>)), PBRS_K((k_shadow<false, 140u>)), PBRS_K((k_shadow<false, 141u>)),
+#endif
 #ifdef PBRS_DEV_OVERRIDES
         PBRS_K((k_extend<false, 20u>)), PBRS_K((k_extend<false, 21u>)), PBRS_K((k_extend<false, 22u>)), PBRS_K((k_extend<false, 23u>)),
         PBRS_K((k_extend<false, 28u>)), PBRS_K((k_extend<false, 29u>)), PBRS_K((k_extend<false, 30u>)), PBRS_K((k_extend<false, 31u>)),
@@ -1247,10 +1283,16 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     c->wide_shadow = c->shadow_flat && wide_ok;
     c->pair_extend = c->pair_shadow = false;
     c->cnode_extend = c->cnode_shadow = false;
+    c->grid_extend = c->grid_shadow = false;
 #ifdef PBRS_DEV_OVERRIDES
     if (const char* e = dev_env("PBRS_WIDE")) {  // developer override (A/B timing): bit 0 k_extend, bit 1 k_shadow
         c->wide_extend = flat_feature != 0u && wide_ok && (std::atoi(e) & 1);
         c->wide_shadow = c->wide_shadow && (std::atoi(e) & 2);
+    }
+    if (const char* e = dev_env("PBRS_GRID")) {  // the binary walks on the compressed records: bit 0 k_extend, bit 1 k_shadow
+        c->grid_extend = flat_feature != 0u && S.fast_slab != 0u && cnodes_ok && (std::atoi(e) & 1);
+        c->grid_shadow = c->shadow_flat && S.fast_slab != 0u && cnodes_ok && (std::atoi(e) & 2);
+        if (c->grid_shadow) c->wide_shadow = false;
     }
     if (const char* e = dev_env("PBRS_CNODE")) {  // ... over the compressed records: bit 0 k_extend, bit 1 k_shadow
         if (flat_feature != 0u && S.fast_slab != 0u && cnodes_ok && (std::atoi(e) & 1)) c->wide_extend = c->cnode_extend = true;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer tool (GPU box): full-size bench lines of library variants built with -DPBRS_DEV_OVERRIDES under PBRS_PAIR / PBRS_WIDE
-# settings (bit 0 k_extend, bit 1 k_shadow), parity window on.   usage: CFGS="c4" tools/ab_pair.sh lib "PBRS_CNODE=3" "PBRS_PAIR=3" "PBRS_WIDE=2" ...
+# settings (bit 0 k_extend, bit 1 k_shadow), parity window on.   usage: CFGS="c4" tools/ab_pair.sh lib "PBRS_GRID=3" "PBRS_CNODE=3" "PBRS_PAIR=3" "PBRS_WIDE=2" ...
 cfgs=${CFGS:-c4}
 lib=$1; shift
 for c in $cfgs; do for v in "$@"; do
