@@ -285,6 +285,53 @@ struct FlatScan {
         }
         return mine;
     }
+    // The same for a closest-hit walk, whose scan only FILTERS (an infinite extent; the reference's test of a leaf's box is made when
+    // the leaf's turn comes, ClosestWalk::node_step): the conservative f32 filter of include/pbrs_numeric.h — it passes whenever the
+    // exact test passes, in 57 instead of 120 issue cycles per box — and three pulled reciprocals instead of six pulled halves.
+    PD static uint32_t run_filter(const DevScene& S, bool fresh, const RaySpace& R, uint32_t& tested) {
+        const uint64_t m = __ballot(fresh);
+        if (m == 0) return 0u;
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t H = (S.n_flat + 1u) >> 1;
+        const uint32_t total = (uint32_t)__popcll(m) * H;
+        const uint32_t rank = lane_prefix(m);
+        const uint32_t list = (uint32_t)__builtin_amdgcn_ds_permute((int)((fresh ? rank : 63u) << 2), (int)lane);
+        const uint32_t magic = (65536u + H - 1u) / H;
+        const f3 r32 = mk3((float)R.rx, (float)R.ry, (float)R.rz);  // RN32 of the f64 reciprocals: what the filter is proved on
+        uint32_t mine = 0;
+        for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t p = base + lane;
+            const bool valid = p < total;
+            const uint32_t r = (p * magic) >> 16, h = p - r * H;
+            const uint32_t owner = pull(r, list);
+            const f3 oo = mk3(pull(owner, R.o.x), pull(owner, R.o.y), pull(owner, R.o.z));
+            const f3 rr = mk3(pull(owner, r32.x), pull(owner, r32.y), pull(owner, r32.z));
+            bool pass0 = false, pass1 = false;
+            if (valid) {
+                const pbrs_node n0 = load_node(S.nodes + S.flat_off + h);
+                // the planes met first / last on an axis by the sign of the reciprocal (= the direction's)
+                pass0 = pn_slab_filter(rr.x > 0.0f ? n0.min[0] : n0.max[0], rr.y > 0.0f ? n0.min[1] : n0.max[1], rr.z > 0.0f ? n0.min[2] : n0.max[2],
+                                       rr.x > 0.0f ? n0.max[0] : n0.min[0], rr.y > 0.0f ? n0.max[1] : n0.min[1], rr.z > 0.0f ? n0.max[2] : n0.min[2], oo.x, oo.y,
+                                       oo.z, rr.x, rr.y, rr.z, pn_inf()) != 0;
+                tested += 1u;
+                if (h + H < S.n_flat) {
+                    const pbrs_node n1 = load_node(S.nodes + S.flat_off + h + H);
+                    pass1 = pn_slab_filter(rr.x > 0.0f ? n1.min[0] : n1.max[0], rr.y > 0.0f ? n1.min[1] : n1.max[1], rr.z > 0.0f ? n1.min[2] : n1.max[2],
+                                           rr.x > 0.0f ? n1.max[0] : n1.min[0], rr.y > 0.0f ? n1.max[1] : n1.min[1], rr.z > 0.0f ? n1.max[2] : n1.min[2], oo.x,
+                                           oo.y, oo.z, rr.x, rr.y, rr.z, pn_inf()) != 0;
+                    tested += 1u;
+                }
+            }
+            const uint64_t w0 = __ballot(pass0), w1 = __ballot(pass1);
+            const int sft = (int)(rank * H) - (int)base;
+            if (fresh && sft > -(int)H && sft < 64) {
+                const uint64_t a = sft >= 0 ? w0 >> sft : w0 << -sft, b = sft >= 0 ? w1 >> sft : w1 << -sft;
+                const uint32_t keep = (1u << H) - 1u;
+                mine |= ((uint32_t)a & keep) | (((uint32_t)b & keep) << H);
+            }
+        }
+        return mine;
+    }
 };
 
 // FlatScan::run with an infinite extent that also leaves, for every leaf that passed, the exact entry distance t_low in the
@@ -396,7 +443,11 @@ struct ClosestWalk {
     PD void scan_wave(const DevScene& S, Cnt<STATS>& cnt) {
         if (!(FEAT & PBRS_FEAT_FLAT_TLAS)) return;
         uint32_t tested = 0;
+#ifdef PBRS_EXACT_CLOSEST_SCAN
         const uint32_t mine = FlatScan::run(S, mode == PBRS_WALK_SCAN, C, pn_inf(), tested);
+#else
+        const uint32_t mine = FlatScan::run_filter(S, mode == PBRS_WALK_SCAN, C, tested);
+#endif
         if (STATS) cnt.c.tlas_nodes += tested;
         if (mode == PBRS_WALK_SCAN) {
             cand = mine;
