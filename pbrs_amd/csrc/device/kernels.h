@@ -210,6 +210,35 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 // waves.  kp[]: 0 loop rounds, 1 refills, 2 rays started, 3 boundary-step executions, 4 lanes in them, 5 / 6 / 7 lanes in a round's first /
 // second / third node step, 8 leaf-step executions, 9 lanes holding a leaf in them, 10 lanes with a walk at the start of a round,
 // 11 rounds whose first node step had a lane; then the walks' own eight counters (traverse.h).  [0]: k_extend, [1]: k_shadow.
+// ... and where a wave's cycles go (-DPBRS_PROBE_TIME, tools/trav_time.py): s_memtime at the boundaries of the loop's regions —
+// 0 refill (retire, fetch, start, scan), 1 boundary step (with its ballots), 2 node steps, 3 leaf step — summed over the waves.
+#ifdef PBRS_PROBE_TIME
+__device__ unsigned long long g_trav_time[2][8];
+#define PBRS_TT_DECL                                       \
+    unsigned long long tt[4] = {0ull, 0ull, 0ull, 0ull};   \
+    unsigned long long tprev = __builtin_amdgcn_s_memtime()
+#define PBRS_TT(i)                                                      \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        tt[i] += now_ - tprev;                                          \
+        tprev = now_;                                                   \
+    } while (0)
+#define PBRS_TT_FLUSH(which)                                                             \
+    do {                                                                                 \
+        if ((threadIdx.x & 63u) == 0u)                                                   \
+            for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_trav_time[which][k_], tt[k_]);   \
+    } while (0)
+#else
+#define PBRS_TT_DECL \
+    do {             \
+    } while (0)
+#define PBRS_TT(i) \
+    do {           \
+    } while (0)
+#define PBRS_TT_FLUSH(which) \
+    do {                     \
+    } while (0)
+#endif
 #ifdef PBRS_PROBE_TRAV
 __device__ unsigned long long g_trav_probe[2][24];
 #define PBRS_KP_DECL(walk)      \
@@ -275,11 +304,13 @@ PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
                 if (walk.mode == PBRS_WALK_XFER) walk.xfer_step(S, stk, cnt);                                   \
             }                                                                                                  \
         }                                                                                                      \
+        PBRS_TT(1);                                                                                            \
         PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                                      \
         PBRS_KP_LANE(5, walk.mode == PBRS_WALK_NODE);                                                          \
         if (__ballot(walk.mode == PBRS_WALK_NODE)) PBRS_KP_WAVE(11);                                           \
         if ((NSTEPS) != 0u && walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                        \
         PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS);                                                              \
+        PBRS_TT(2);                                                                                            \
         const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                         \
         if (nl && (nl >= LEAF_MIN || __ballot(walk.mode == PBRS_WALK_NODE) == 0)) {                            \
             PBRS_PROBE_LEAF_COUNT(cnt);                                                                        \
@@ -287,6 +318,7 @@ PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
             PBRS_KP_LANE(9, walk.mode == PBRS_WALK_LEAF);                                                      \
             walk.leaf_wave(S, cnt);                                                                            \
         }                                                                                                      \
+        PBRS_TT(3);                                                                                            \
     } while (0)
 // developer probe (tools/util_probe.py, instrumented variant only): wave-level executions of the node and leaf steps,
 // stashed in the cuboid / disk counters of a scene that has neither
@@ -485,6 +517,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
     constexpr bool GRID = !STATS && ARITY == 0u && (FEAT & PBRS_FEAT_GRID) != 0u;
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
+    PBRS_TT_DECL;
     uint32_t item = 0;  // queue position of the lane's ray
     WaveWork work = wave_work_init(n);
     for (;;) {
@@ -546,11 +579,13 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
                 break;
             }
         }
+        PBRS_TT(0);
         PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY));
         if constexpr (WIDE || GRID) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
     if (!STATS) PBRS_KP_FLUSH(0, walk);
+    if (!STATS) PBRS_TT_FLUSH(0);
 }
 
 // Developer probe (tools/shade_probe.py; -DPBRS_PROBE_SHADE builds only): wall cycles of k_shade's regions, summed per wave.
@@ -1180,6 +1215,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
     constexpr bool GRID = !STATS && ARITY == 0u && (FEAT & PBRS_FEAT_GRID) != 0u;
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
+    PBRS_TT_DECL;
     uint32_t item = 0, rec = 0;
     WaveWork work = wave_work_init(n);
     for (;;) {
@@ -1232,11 +1268,13 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
                 break;
             }
         }
+        PBRS_TT(0);
         PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY));
         if constexpr (WIDE || GRID) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, 0u);
     if (!STATS) PBRS_KP_FLUSH(1, walk);
+    if (!STATS) PBRS_TT_FLUSH(1);
 }
 
 // The radiance add of uniform_sample_one_light / path_integrator for paths whose estimate had to wait for

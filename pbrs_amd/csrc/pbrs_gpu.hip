@@ -905,6 +905,15 @@ int pbrs_debug_shade_probe(unsigned long long* out16) {
 }
 #endif
 
+#ifdef PBRS_PROBE_TIME
+// developer probe: reads and clears the traversal loops' cycle sums by region ([0]: k_extend, [1]: k_shadow; kernels.h)
+int pbrs_debug_trav_time(unsigned long long* out16) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_trav_time), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long zero[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trav_time), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef PBRS_PROBE_TRAV
 // developer probe: reads and clears the traversal loops' event counts ([0]: k_extend, [1]: k_shadow; kernels.h)
 int pbrs_debug_trav_probe(unsigned long long* out48) {
