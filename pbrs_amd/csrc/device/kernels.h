@@ -278,6 +278,17 @@ PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
 // boundary, who holds a leaf, who is done) then run a third as often.  C4 (23 levels), ms per frame extend / shadow at
 // 1 / 2 / 3 / 4 / 6 steps: 562 / 530 / 523 / 523 / 537 and 321 / 301 / 295 / 295 / 301; short walks lose (two steps: C2 -2 %,
 // C3 -1 %: the later steps run at few lanes) and keep one.
+#ifdef PBRS_FULL_FURTHER_STEPS  /* A/B: every node step of a round is the full one */
+#define PBRS_FURTHER_NODE_STEP(walk, S, stk, cnt) walk.node_step(S, stk, cnt)
+#define PBRS_FIRST_NODE_STEP(walk, S, stk, cnt) walk.node_step(S, stk, cnt)
+#else
+#define PBRS_FURTHER_NODE_STEP(walk, S, stk, cnt) walk.node_step_fast(S, stk, cnt)
+#ifdef PBRS_FLOOR_FIRST_STEP  /* A/B: a floor step, then lean steps only — measured even on C4 (444.3 against 444.0 ms), 2 % behind on C2 */
+#define PBRS_FIRST_NODE_STEP(walk, S, stk, cnt) walk.first_node_step(S, stk, cnt)
+#else
+#define PBRS_FIRST_NODE_STEP(walk, S, stk, cnt) walk.node_step(S, stk, cnt)
+#endif
+#endif
 #define PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS)                            \
     do {                                                                           \
         if ((NSTEPS) == 0u && __ballot(walk.mode == PBRS_WALK_NODE)) { /* as long as most of the wave wants one: a loop of its own, whose registers the allocator serves first */ \
@@ -288,7 +299,7 @@ PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
         }                                                                          \
         _Pragma("unroll") for (uint32_t k_ = 1; k_ < (NSTEPS); ++k_) {             \
             PBRS_KP_LANE(5 + (k_ < 2u ? k_ : 2u), walk.mode == PBRS_WALK_NODE);    \
-            if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);          \
+            if (walk.mode == PBRS_WALK_NODE) PBRS_FURTHER_NODE_STEP(walk, S, stk, cnt); \
         }                                                                          \
     } while (0)
 #define PBRS_STEP_WALK(walk, S, stk, cnt, XFER_MIN, LEAF_MIN, NSTEPS)                                                  \
@@ -308,7 +319,7 @@ PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
         PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                                      \
         PBRS_KP_LANE(5, walk.mode == PBRS_WALK_NODE);                                                          \
         if (__ballot(walk.mode == PBRS_WALK_NODE)) PBRS_KP_WAVE(11);                                           \
-        if ((NSTEPS) != 0u && walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                        \
+        if ((NSTEPS) != 0u && walk.mode == PBRS_WALK_NODE) PBRS_FIRST_NODE_STEP(walk, S, stk, cnt);            \
         PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS);                                                              \
         PBRS_TT(2);                                                                                            \
         const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                         \

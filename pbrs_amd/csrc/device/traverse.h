@@ -544,6 +544,75 @@ struct ClosestWalk {
         }
     }
 
+    // What a round does before its node steps for the lanes whose stack is down to the floor of their tree: the instance is used
+    // up (the boundary step, or the end of the walk), or — at the TLAS level of a scanned TLAS — the next scanned leaf goes onto the
+    // stack, where the node step finds it like any other node (its box gets the reference's test of that moment), or the walk is
+    // over.  No load, no box test: a dozen instructions once per round instead of exec-mask bookkeeping in every node step.
+    PD void floor_step(const DevScene& S, LaneStack stk) {
+        if (in_blas) {
+            if (sp == blas_base) mode = exit_mode();
+            return;
+        }
+        if (sp != 0) return;
+        if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || cand == 0u) {
+            mode = PBRS_WALK_DONE;
+            return;
+        }
+        stk.put(sp++, S.flat_off + (uint32_t)__builtin_ctz(cand));
+        cand &= cand - 1u;
+    }
+    // A round's first node step: the instrumented and the GRID walks keep the one-piece step (its counters tell scanned leaves from
+    // walked TLAS nodes; its TLAS level is not a stack level)
+    PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        if constexpr (STATS || GRID) {
+            node_step(S, stk, cnt);
+        } else {
+            floor_step(S, stk);
+            if (mode == PBRS_WALK_NODE) node_step_fast(S, stk, cnt);
+        }
+    }
+    // A round's FURTHER node steps (kernels.h, PBRS_MORE_NODE_STEPS): the common case only — a pending entry of the tree the lane is
+    // in is popped and tested.  A lane whose stack is down to the floor of its tree (the instance used up, the next scanned TLAS
+    // leaf, the end of the walk) sits the step out and lets the round's first step, which has the code for all that, take it: the
+    // second and third copies of the step carry a third fewer scalar instructions (exec-mask bookkeeping of branches that nearly
+    // every execution took for one or two lanes).
+    PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        if (GRID || sp == (in_blas ? blas_base : 0)) {
+            if (GRID) node_step(S, stk, cnt);
+            return;
+        }
+        PBRS_TP(0);
+        const uint32_t ni = stk.get(--sp);
+        if (STATS) {
+            if (in_blas) CNT(blas_nodes);
+            else CNT(tlas_nodes);
+        }
+        const pbrs_node node = load_node(S.nodes + ni);
+        PBRS_TP(1);
+        if (!slab_rs(node, C, lt)) {
+            PBRS_TP(2);
+            return;
+        }
+        if (!(node.b & PBRS_LEAF_FLAG)) {
+            bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
+            uint32_t left = ni + 1, right = node.a;
+            stk.put(sp++, left_first ? right : left);
+            stk.put(sp++, left_first ? left : right);
+            lt = in_blas ? mt : lt;
+        } else if (in_blas) {
+            PBRS_TP(3);
+            PBRS_TP(4);
+            leaf_a = node.a;
+            leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
+            if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
+            else lt = mt;  // an empty leaf still runs blas.rs:468
+        } else {  // a TLAS leaf: enter the instance (xfer_step)
+            cur_inst = node.a;
+            inst_info = (node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+            mode = PBRS_WALK_XFER;
+        }
+    }
+
     // Instance boundary, both directions.  Any one lane crosses a boundary in few of its steps, but some lane of a wave
     // does in nearly every round; inline, this code (ray transform, reciprocals, scratch traffic) ran for a handful of
     // lanes each round.  As a state of its own the kernel runs it when enough lanes wait at a boundary (k_extend).
@@ -881,6 +950,65 @@ struct AnyWalk {
             mode = PBRS_WALK_XFER;
         }
     }
+    PD void floor_step(const DevScene& S, LaneStack stk) {  // see ClosestWalk::floor_step; a scanned leaf's box has passed already
+        if (in_blas) {
+            if (sp == blas_base) mode = exit_mode();
+            return;
+        }
+        if (sp != 0) return;
+        if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || cand == 0u) {
+            mode = PBRS_WALK_DONE;
+            return;
+        }
+        const uint32_t k = (uint32_t)__builtin_ctz(cand);
+        cand &= cand - 1u;
+        const pbrs_node leaf = load_node(S.nodes + S.flat_off + k);
+        leaf_a = leaf.a;
+        inst_kind = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+        mode = PBRS_WALK_XFER;
+    }
+    PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        if constexpr (STATS || GRID) {
+            node_step(S, stk, cnt);
+        } else {
+            floor_step(S, stk);
+            if (mode == PBRS_WALK_NODE) node_step_fast(S, stk, cnt);
+        }
+    }
+    PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {  // see ClosestWalk::node_step_fast
+        if (GRID || sp == (in_blas ? blas_base : 0)) {
+            if (GRID) node_step(S, stk, cnt);
+            return;
+        }
+        PBRS_TP(0);
+        const uint32_t ni = stk.get(--sp);
+        const pbrs_node node = load_node(S.nodes + ni);
+        if (STATS) {
+            if (in_blas) CNT(blas_nodes);
+            else CNT(tlas_nodes);
+        }
+        PBRS_TP(1);
+        if (!slab_rs(node, C, t_max)) {
+            PBRS_TP(2);
+            return;
+        }
+        if (!(node.b & PBRS_LEAF_FLAG)) {
+            bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
+            uint32_t left = ni + 1, right = node.a;
+            stk.put(sp++, left_first ? right : left);
+            stk.put(sp++, left_first ? left : right);
+        } else if (in_blas) {
+            PBRS_TP(3);
+            PBRS_TP(4);
+            leaf_a = node.a;
+            leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
+            if (leaf_end != leaf_a) mode = PBRS_WALK_LEAF;
+        } else {
+            leaf_a = node.a;
+            inst_kind = (node.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
+            mode = PBRS_WALK_XFER;
+        }
+    }
     // Instance::occludes (instance.rs:68-72) and the return from it; see ClosestWalk::xfer_step.
     PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
         mode = PBRS_WALK_NODE;
@@ -1132,6 +1260,8 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             if (sp == 0) mode = B::exit_mode();
         }
     }
+    PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
+    PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
         PBRS_TP(0);
         if constexpr (ARITY == 1u) {
@@ -1405,6 +1535,8 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             if (sp == 0) mode = B::exit_mode();
         }
     }
+    PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
+    PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
         PBRS_TP(0);
         if constexpr (ARITY == 1u) {
