@@ -577,7 +577,7 @@ struct ClosestWalk {
     // second and third copies of the step carry a third fewer scalar instructions (exec-mask bookkeeping of branches that nearly
     // every execution took for one or two lanes).
     PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
-        if (GRID || sp == (in_blas ? blas_base : 0)) {
+        if (GRID || sp == (in_blas ? blas_base : 0) || !C.fast) {  // (a ray on the literal divisions: the first step's, too)
             if (GRID) node_step(S, stk, cnt);
             return;
         }
@@ -589,7 +589,9 @@ struct ClosestWalk {
         }
         const pbrs_node node = load_node(S.nodes + ni);
         PBRS_TP(1);
-        if (!slab_rs(node, C, lt)) {
+        RaySpace F = C;
+        F.fast = true;  // known here: this copy of the box test carries no division path
+        if (!slab_rs(node, F, lt)) {
             PBRS_TP(2);
             return;
         }
@@ -976,7 +978,7 @@ struct AnyWalk {
         }
     }
     PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {  // see ClosestWalk::node_step_fast
-        if (GRID || sp == (in_blas ? blas_base : 0)) {
+        if (GRID || sp == (in_blas ? blas_base : 0) || !C.fast) {
             if (GRID) node_step(S, stk, cnt);
             return;
         }
@@ -988,7 +990,9 @@ struct AnyWalk {
             else CNT(tlas_nodes);
         }
         PBRS_TP(1);
-        if (!slab_rs(node, C, t_max)) {
+        RaySpace F = C;
+        F.fast = true;
+        if (!slab_rs(node, F, t_max)) {
             PBRS_TP(2);
             return;
         }
@@ -1260,7 +1264,12 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             if (sp == 0) mode = B::exit_mode();
         }
     }
-    PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
+    // a round's further node steps: a lane with nothing to take from its register or its stack (the next scanned TLAS leaf, the end
+    // of a mesh or of the walk: the first step's business) sits them out — see ClosestWalk::node_step_fast
+    PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
+        if (cur == PBRS_WREF_NONE && sp == 0) return;
+        node_step(S, stk, cnt);
+    }
     PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
         PBRS_TP(0);
@@ -1535,7 +1544,12 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             if (sp == 0) mode = B::exit_mode();
         }
     }
-    PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
+    // a round's further node steps: a lane with nothing to take from its register or its stack (the next scanned TLAS leaf, the end
+    // of a mesh or of the walk: the first step's business) sits them out — see ClosestWalk::node_step_fast
+    PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
+        if (cur == PBRS_WREF_NONE && sp == 0) return;
+        node_step(S, stk, cnt);
+    }
     PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
         PBRS_TP(0);
