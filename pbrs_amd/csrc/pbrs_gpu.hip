@@ -88,6 +88,7 @@ struct pbrs_ctx {
     bool textured = false;  // the uploaded scene evaluates non-Solid textures: k_shade<.., true>
     bool fourier = false;   // ... has a Fourier BSDF lobe: k_shade<.., true, PBRS_SHADE_FOURIER>
     uint32_t lambert_class = 0;    // shading class of the Lambert-only materials (0: none)
+    uint32_t fourier_class = 0;    // shading class of the Fourier BSDF materials (0: none): k_shade's variants with that lobe run over it alone
     uint32_t light_spec = 0;       // PBRS_SHADE_LIGHT_*: every area light has that shape
     bool split_lambert = true;     // PBRS_SPLIT_LAMBERT=0 in the environment: one general k_shade launch for all classes (A/B timing)
     uint32_t shade_spec = 0;       // PBRS_SHADE_*: what k_shade<PATH> may leave out for this scene
@@ -109,6 +110,7 @@ struct pbrs_ctx {
     uint32_t* slow = nullptr;      // 2 * cap_slots: queue positions a wide-walk kernel handed to the binary-walk kernel
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
     bool sort_classes = true;      // PBRS_SORT_CLASSES=0 in the environment turns the class sort off (A/B timing)
+    bool split_fourier = true;     // PBRS_SPLIT_FOURIER=0 in developer builds: one launch of the Fourier variants over every class, as in round 2
     uint64_t pending_closest = 0;
 };
 
@@ -685,11 +687,14 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         // ... and where one of the classes is Lambertian (and the integrator has a Lambert variant), class-major over the whole
         // queue, so that the class gets a launch of that variant and the other classes one of the general kernel
         const bool split = sorted && c->lambert_class && c->split_lambert && !c->textured && !c->fourier && rc.integrator == PBRS_INTEGRATOR_PATH;
+        // ... or a Fourier BSDF: its lobe's code (168 registers and scratch in k_shade's variants that carry it) then runs over
+        // the vertices on such a material only, the other classes take the kernels without it
+        const bool fsplit = sorted && c->fourier && c->fourier_class && c->split_fourier && rc.integrator <= PBRS_INTEGRATOR_DIRECT;
         const uint32_t n_tiles = (N + PBRS_SORT_TILE - 1) / PBRS_SORT_TILE;
-        if (split || qsplit) {  // class-major over the whole queue; a queue k_extend split: class 1 = the kept paths, last
+        if (split || qsplit || fsplit) {  // class-major over the whole queue; a queue k_extend split: class 1 = the kept paths, last
             if (qsplit) hipLaunchKernelGGL(k_class_count<2u>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
             else hipLaunchKernelGGL(k_class_count<PBRS_MAX_CLASSES>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
-            hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64 * PBRS_MAX_CLASSES), 0, c->stream, c->st, cnt_in, N, qsplit ? 1u : c->lambert_class,
+            hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64 * PBRS_MAX_CLASSES), 0, c->stream, c->st, cnt_in, N, qsplit ? 1u : fsplit ? c->fourier_class : c->lambert_class,
                                (qsplit && c->split_decision == 0) ? c->bounce_acc + 2 * PBRS_STATS_MAX_BOUNCES : nullptr);
             if (qsplit) hipLaunchKernelGGL(k_class_scatter<2u>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
             else hipLaunchKernelGGL(k_class_scatter<PBRS_MAX_CLASSES>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
@@ -710,6 +715,18 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_MATERIALS, false, 0u);
             } else if (rc.integrator == PBRS_INTEGRATOR_NORMALS) {
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_NORMALS, false, 0u);
+            } else if (c->fourier && fsplit) {  // the Fourier materials' class under the kernels that carry the lobe, the rest without
+                shade_range = c->st.class_range + c->fourier_class;
+                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true, PBRS_SHADE_FOURIER);
+                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true, PBRS_SHADE_FOURIER);
+                shade_range = c->st.class_range + PBRS_MAX_CLASSES;
+                if (c->textured) {
+                    if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true, 0u);
+                    else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true, 0u);
+                } else {
+                    if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, false, 0u);
+                    else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, 0u);
+                }
             } else if (c->fourier) {  // some material is a Fourier BSDF: the kernels that carry the lobe (and textures)
                 if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true, PBRS_SHADE_FOURIER);
                 else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true, PBRS_SHADE_FOURIER);
@@ -938,6 +955,7 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     c->stream = c->own_stream;
     if (const char* e = dev_env("PBRS_SORT_CLASSES")) c->sort_classes = std::atoi(e) != 0;
     if (const char* e = dev_env("PBRS_SPLIT_LAMBERT")) c->split_lambert = std::atoi(e) != 0;
+    if (const char* e = dev_env("PBRS_SPLIT_FOURIER")) c->split_fourier = std::atoi(e) != 0;
     if (const char* e = dev_env("PBRS_SPLIT_QUEUE")) c->split_queue = std::atoi(e) != 0;
     for (int k = 0; ok && k < 2; ++k) {
         hipEvent_t ev = nullptr;
@@ -1156,6 +1174,11 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             const std::string lam_sig = {(char)('a' + PBRS_BXDF_DIFFUSE), 'a', 'a', 'a', '-'};
             for (size_t at = 0; at < sigs.size() && at + 1 < PBRS_MAX_CLASSES - 1; ++at)
                 if (sigs[at] == lam_sig) c->lambert_class = (uint32_t)at + 1;
+            // ... and of the materials that are one Fourier BSDF (material/src/lib.rs:451-475: whatever their tables, one signature)
+            c->fourier_class = 0;
+            const std::string fou_sig = {(char)('a' + PBRS_BXDF_FOURIER), 'a', 'a', 'a', '-'};
+            for (size_t at = 0; at < sigs.size() && at + 1 < PBRS_MAX_CLASSES - 1; ++at)
+                if (sigs[at] == fou_sig) c->fourier_class = (uint32_t)at + 1;
         }
         for (pbrs_instance& in : inst) {
             in.pad[0] = mat_class[in.material];
