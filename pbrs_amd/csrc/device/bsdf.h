@@ -158,7 +158,7 @@ PD f3 beckmann_sample_wh(float ax, float ay, f3 wo, float u, float v) {         
 // compile-time constant — in all others.
 PD f3 bxdf_eval(const pbrs_bxdf& b, f3 albedo, f3 wo, f3 wi, bool lam, const FourierView* fv = nullptr) {
     if (lam) return albedo * PN_FRAC_1_PI;
-    if (fv && b.kind == PBRS_BXDF_FOURIER) return fourier_eval(*fv, fv->tables[b.intrusion], wo, wi);  // fourier.rs:300-360
+    if (fv && (fv->only || b.kind == PBRS_BXDF_FOURIER)) return fourier_eval(*fv, fv->tables[b.intrusion], wo, wi);  // fourier.rs:300-360
     if (b.kind == PBRS_BXDF_SPECULAR) return gray(0.0f);  // :458-460
     if (b.kind == PBRS_BXDF_DIFFUSE) {                    // :540-559
         if (!b.oren_nayar) return albedo * PN_FRAC_1_PI;
@@ -189,7 +189,7 @@ PD f3 bxdf_eval(const pbrs_bxdf& b, f3 albedo, f3 wo, f3 wi, bool lam, const Fou
            pn_weak_recip(4.0f * cos_theta_o * cos_theta_i);
 }
 PD ProbD bxdf_prob(const pbrs_bxdf& b, f3 wo, f3 wi, bool lam, const FourierView* fv = nullptr) {
-    if (fv && b.kind == PBRS_BXDF_FOURIER) return fourier_prob(*fv, fv->tables[b.intrusion], wo, wi);  // fourier.rs:442-485
+    if (fv && (fv->only || b.kind == PBRS_BXDF_FOURIER)) return fourier_prob(*fv, fv->tables[b.intrusion], wo, wi);  // fourier.rs:442-485
     if (!lam && b.kind == PBRS_BXDF_SPECULAR) return mass(0.0f);  // :503-505
     if (lam || b.kind == PBRS_BXDF_DIFFUSE) {                    // :566-572
         if (wo.z * wi.z >= 0.0f) return density(wi.z * PN_FRAC_1_PI);
@@ -230,7 +230,7 @@ PD void specular_refract(const pbrs_bxdf& b, f3 albedo, f3 wo, f3& wi, f3& f) { 
 }
 PD void bxdf_sample(const pbrs_bxdf& b, f3 albedo, f3 wo, float r0, float r1, f3& f, f3& wi, ProbD& pr, bool lam,
                     const FourierView* fv = nullptr) {
-    if (fv && b.kind == PBRS_BXDF_FOURIER) {  // fourier.rs:362-440, rnd2 = (u, v)
+    if (fv && (fv->only || b.kind == PBRS_BXDF_FOURIER)) {  // fourier.rs:362-440, rnd2 = (u, v)
         fourier_sample(*fv, fv->tables[b.intrusion], wo, r0, r1, f, wi, pr);
         return;
     }
@@ -309,8 +309,10 @@ PD Bsdf bsdf_new_frame(const Isect& is, const pbrs_bxdf* lobes, uint32_t n) {  /
 PD f3 world_to_local(const Bsdf& b, f3 w) { return hat(mk3(dot(b.c0, w), dot(b.c1, w), dot(b.c2, w))); }  // :114-118
 PD f3 local_to_world(const Bsdf& b, f3 l) { return l.x * b.c0 + l.y * b.c1 + l.z * b.c2; }                 // :120-124
 // src/bsdf.rs:104-113: the first Specular lobe sampled with rnd2 = (0.0, 0.0); false when the material has none
+// A kernel specialised on materials of ONE lobe that is not Specular (k_shade's PBRS_SHADE_LAMBERT and PBRS_SHADE_FOURIER_ONLY variants)
+PD bool one_plain_lobe(const Bsdf& b) { return b.lam || (b.fourier && b.fourier->only); }
 PD bool bsdf_sample_specular(const Bsdf& b, f3 wo_world, f3& f, f3& wi_out, ProbD& pr) {
-    if (b.lam) return false;
+    if (one_plain_lobe(b)) return false;
     f3 wo = world_to_local(b, wo_world);
     for (uint32_t i = 0; i < b.n; ++i) {
         if (b.lobe(i).kind == PBRS_BXDF_SPECULAR) {
@@ -359,7 +361,7 @@ PD void bsdf_sample_l(const Bsdf& b, f3 wo, float u, float v, f3& f, f3& wi_out,
         return;
     }
     // `swap_remove(chosen)`: the others are visited as [0 .. chosen-1, last, chosen+1 .. n-2].
-    uint32_t others = b.lam ? 0u : b.n - 1;  // lam: one lobe at most
+    uint32_t others = one_plain_lobe(b) ? 0u : b.n - 1;  // one lobe at most
     uint32_t count = 0;
     float other_pdf_sum = 0.0f;
     f3 other_f = gray(0.0f);

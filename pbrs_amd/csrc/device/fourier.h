@@ -19,6 +19,8 @@ struct FourierView {  // where the tables of the scene are (DevScene): nullptr m
     const pbrs_fourier_table* tables;
     const float* F;
     const uint32_t* W;
+    bool only;  // every lobe the kernel meets is a Fourier lobe (k_shade's PBRS_SHADE_FOURIER_ONLY variants, launched over the Fourier
+                // materials' class): a compile-time constant there — the other lobe kinds' code is gone, a lobe's kind is not read
 };
 
 // math/src/spline.rs:161-185 with `predicate(i) = nodes[i] <= x`; its asserts are panic sites upstream (NaN operands)

@@ -636,6 +636,9 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 //   PBRS_SHADE_FOURIER        the other way round: some material is a Fourier BSDF (device/fourier.h), whose code only the
 //                             kernels with this bit contain (its f64 series sums and Newton loops are long and register-hungry)
 #define PBRS_SHADE_FOURIER 8u
+//   PBRS_SHADE_FOURIER_ONLY   (with PBRS_SHADE_FOURIER) every vertex the launch meets is on a Fourier material, whose one lobe is the
+//                             Fourier BSDF: the launch over that class of a class-major queue (pbrs_gpu.hip)
+#define PBRS_SHADE_FOURIER_ONLY 16u
 template <uint32_t INTEG, bool TEX, uint32_t SPEC>
 __global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
                                               uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count, uint32_t sorted, const uint2* range) {
@@ -788,7 +791,7 @@ __global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : 
 #endif
             Bsdf bs = bsdf_new_frame(is, S.bxdfs + mat->first_bxdf, mat->n_bxdfs);
             bs.lam = (SPEC & PBRS_SHADE_LAMBERT) != 0u;
-            const FourierView fourier_view{S.fourier, S.tex_floats, S.tex_words};
+            const FourierView fourier_view{S.fourier, S.tex_floats, S.tex_words, (SPEC & PBRS_SHADE_FOURIER_ONLY) != 0u};
             bs.fourier = (SPEC & PBRS_SHADE_FOURIER) ? &fourier_view : nullptr;
             if (TEX && (mat->flags & PBRS_MATERIAL_TEXTURED)) {
                 // `mtl.bxdfs_at(&hit)` with non-Solid textures (material/src/lib.rs:180-184, :317-365): evaluate each

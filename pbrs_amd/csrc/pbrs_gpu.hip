@@ -716,9 +716,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
             } else if (rc.integrator == PBRS_INTEGRATOR_NORMALS) {
                 PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_NORMALS, false, 0u);
             } else if (c->fourier && fsplit) {  // the Fourier materials' class under the kernels that carry the lobe, the rest without
-                shade_range = c->st.class_range + c->fourier_class;
-                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true, PBRS_SHADE_FOURIER);
-                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true, PBRS_SHADE_FOURIER);
+                shade_range = c->st.class_range + c->fourier_class;  // (one untextured Fourier lobe per material: the variant cut down to it)
+                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, false, PBRS_SHADE_FOURIER | PBRS_SHADE_FOURIER_ONLY);
+                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_FOURIER | PBRS_SHADE_FOURIER_ONLY);
                 shade_range = c->st.class_range + PBRS_MAX_CLASSES;
                 if (c->textured) {
                     if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true, 0u);
