@@ -19,6 +19,8 @@ struct FourierView {  // where the tables of the scene are (DevScene): nullptr m
     const pbrs_fourier_table* tables;
     const float* F;
     const uint32_t* W;
+    float* ak;        // per-lane LDS column (entry k at ak[k * 256]) for the luminance series of a sampled direction pair, or nullptr
+    uint32_t ak_cap;  // ... and its rows
     bool only;  // every lobe the kernel meets is a Fourier lobe (k_shade's PBRS_SHADE_FOURIER_ONLY variants, launched over the Fourier
                 // materials' class): a compile-time constant there — the other lobe kinds' code is gone, a lobe's kind is not read
 };
@@ -192,12 +194,13 @@ PD ProbD fourier_prob(const FourierView& V, const pbrs_fourier_table& T, f3 wo, 
     return density(rho == 0.0f ? 0.0f : y / rho);
 }
 
-// sample_fourier (:245-297) over the luminance series of N (n >= 1 terms)
-PD void sample_fourier(const FourierNbrs& N, uint32_t n, const float* recip, float u, float& f_out, float& phi_out, float& pdf_out) {
+// sample_fourier (:245-297) over the luminance series coef(k), k < n (n >= 1 terms)
+template <typename Coef>
+PD void sample_fourier_t(Coef coef, uint32_t n, const float* recip, float u, float& f_out, float& phi_out, float& pdf_out) {
     const bool flip = u >= 0.5f;
     u = flip ? 1.0f - 2.0f * (u - 0.5f) : u * 2.0f;
     const double PI64 = 3.14159265358979323846264338327950288, FRAC_1_PI64 = 0.318309886183790671537767526745028724;
-    const float ak0 = N.coef_oi(0u, 0u);
+    const float ak0 = coef(0u);
     double left = 0.0, right = PI64, phi = 0.5 * PI64, sampled_f = 0.0;
     for (int it = 0; it < PBRS_FOURIER_MAX_ITERATIONS; ++it) {
         double sin_phi, cos_phi;
@@ -208,7 +211,7 @@ PD void sample_fourier(const FourierNbrs& N, uint32_t n, const float* recip, flo
             const double next_sin = 2.0 * cos_phi * cur_sin - prev_sin;
             const double next_cos = 2.0 * cos_phi * cur_cos - prev_cos;
             prev_cos = cur_cos, cur_cos = next_cos, prev_sin = cur_sin, cur_sin = next_sin;
-            const float akk = N.coef_oi(0u, k);
+            const float akk = coef(k);
             f_integral += (double)(akk * recip[k]) * next_sin;
             f += (double)akk * next_cos;
         }
@@ -224,6 +227,18 @@ PD void sample_fourier(const FourierNbrs& N, uint32_t n, const float* recip, flo
     pdf_out = (float)(sampled_f * FRAC_1_PI64 * 0.5) / ak0;
     f_out = (float)sampled_f;
     phi_out = (float)phi;
+}
+// The Newton-bisection loop reads the whole series once per iteration: where the kernel has a per-lane LDS column for it (the
+// Fourier-only variants of k_shade) and the series fits, a_k is interpolated ONCE — the same f32 sums, stored and read back
+// unchanged — instead of once per iteration (16 neighbours x three loads per term).
+PD void sample_fourier(const FourierView& V, const FourierNbrs& N, uint32_t n, const float* recip, float u, float& f_out, float& phi_out, float& pdf_out) {
+    if (V.ak && n <= V.ak_cap) {
+        for (uint32_t k = 0; k < n; ++k) V.ak[k * 256u] = N.coef_oi(0u, k);
+        const float* ak = V.ak;
+        sample_fourier_t([ak](uint32_t k) { return ak[k * 256u]; }, n, recip, u, f_out, phi_out, pdf_out);
+    } else {
+        sample_fourier_t([&N](uint32_t k) { return N.coef_oi(0u, k); }, n, recip, u, f_out, phi_out, pdf_out);
+    }
 }
 
 PD float polynomial4(float x, float c0, float c1, float c2, float c3) { return ((((0.0f * x + c3) * x + c2) * x + c1) * x + c0); }
@@ -302,7 +317,7 @@ PD void fourier_sample(const FourierView& V, const pbrs_fourier_table& T, f3 wo,
         phi = u * 2.0f * PN_PI;
         pdf_phi = PN_FRAC_1_PI;
     } else {
-        sample_fourier(N, m_max, V.F + T.recip, u, y, phi, pdf_phi);
+        sample_fourier(V, N, m_max, V.F + T.recip, u, y, phi, pdf_phi);
     }
     const float pdf = pn_max(pdf_phi * pdf_mu, 0.0f);
     const float sin2_theta_i = pn_max(1.0f - mu_i * mu_i, 0.0f);

@@ -639,12 +639,18 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 //   PBRS_SHADE_FOURIER_ONLY   (with PBRS_SHADE_FOURIER) every vertex the launch meets is on a Fourier material, whose one lobe is the
 //                             Fourier BSDF: the launch over that class of a class-major queue (pbrs_gpu.hip)
 #define PBRS_SHADE_FOURIER_ONLY 16u
+#ifndef PBRS_FOURIER_AK_ROWS
+#define PBRS_FOURIER_AK_ROWS 48u  // terms of a luminance series kept in LDS per lane; longer series are recomputed where they are consumed
+#endif
 template <uint32_t INTEG, bool TEX, uint32_t SPEC>
 __global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
                                               uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count, uint32_t sorted, const uint2* range) {
     // per-hit lobe lists of textured materials (Bsdf::hit_lobe / hit_albedo); absent from the untextured instantiation
     __shared__ uint32_t s_hit_lobe[TEX ? PBRS_MAX_BXDFS * 256 : 1];
     __shared__ float s_hit_albedo[TEX ? 3 * PBRS_MAX_BXDFS * 256 : 1];
+    // the luminance series of a sampled Fourier direction pair, one column per lane (device/fourier.h, sample_fourier): 48 KB — three
+    // blocks of the Fourier-only variants, which carry no texture lists, still fit a CU's LDS
+    __shared__ float s_fourier_ak[(SPEC & 16u) ? PBRS_FOURIER_AK_ROWS * 256 : 1];
 #ifdef PBRS_PROBE_SHADE
     unsigned long long probe_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long probe_t = __builtin_amdgcn_s_memtime();
@@ -791,7 +797,8 @@ __global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : 
 #endif
             Bsdf bs = bsdf_new_frame(is, S.bxdfs + mat->first_bxdf, mat->n_bxdfs);
             bs.lam = (SPEC & PBRS_SHADE_LAMBERT) != 0u;
-            const FourierView fourier_view{S.fourier, S.tex_floats, S.tex_words, (SPEC & PBRS_SHADE_FOURIER_ONLY) != 0u};
+            const FourierView fourier_view{S.fourier, S.tex_floats, S.tex_words, (SPEC & PBRS_SHADE_FOURIER_ONLY) ? s_fourier_ak + threadIdx.x : nullptr,
+                                           (SPEC & PBRS_SHADE_FOURIER_ONLY) ? PBRS_FOURIER_AK_ROWS : 0u, (SPEC & PBRS_SHADE_FOURIER_ONLY) != 0u};
             bs.fourier = (SPEC & PBRS_SHADE_FOURIER) ? &fourier_view : nullptr;
             if (TEX && (mat->flags & PBRS_MATERIAL_TEXTURED)) {
                 // `mtl.bxdfs_at(&hit)` with non-Solid textures (material/src/lib.rs:180-184, :317-365): evaluate each

@@ -727,6 +727,9 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
                     if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, false, 0u);
                     else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, 0u);
                 }
+            } else if (c->fourier && c->fourier_class && c->S.n_classes == 1u) {  // every material with lobes is a Fourier BSDF
+                if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, false, PBRS_SHADE_FOURIER | PBRS_SHADE_FOURIER_ONLY);
+                else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_FOURIER | PBRS_SHADE_FOURIER_ONLY);
             } else if (c->fourier) {  // some material is a Fourier BSDF: the kernels that carry the lobe (and textures)
                 if (direct) PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_DIRECT, true, PBRS_SHADE_FOURIER);
                 else PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, true, PBRS_SHADE_FOURIER);
