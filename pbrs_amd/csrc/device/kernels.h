@@ -1430,7 +1430,7 @@ __global__ void __launch_bounds__(256) k_numeric_eval(uint32_t fn, uint32_t n, c
         case 12: r = pn_powi(a, (int)b); break;
         case 13: r = pn_fract(a); break;
         case 14: r = pn_floor(a); break;
-        case 15: r = qdiv(a, recip64((double)b)); break;  // the box test's quotient (traverse.h): must equal a / b in its guarded range
+        case 15: r = qdiv(-a, b, -(1.0f / b)); break;  // the box test's quotient (traverse.h): must equal a / b in its guarded range
         default: break;
     }
     out[i] = r;

@@ -10,16 +10,18 @@
 // wave's lanes, TriShare), or an instance boundary (ray into / out of the instance's space).  The kernels (kernels.h, PBRS_STEP_WALK) run, each round, whichever steps their lanes are
 // waiting for — lanes in different phases of their walks share the instruction stream — and refill finished lanes.
 //
-// Box test.  geometry/src/bvh.rs:84-99 divides six times per node; IEEE f32 division costs ~11
-// instructions on gfx950.  `(float)((double)n * R)` with R = rn64(1/(double)d) IS the correctly rounded
-// f32 quotient whenever no f32 overflow/underflow is involved: the f64 product is within 2^-52 of n/d,
-// while n/d (a ratio of two 24-bit significands) is either exactly an f32 or at least 2^-49 (relative)
-// away from every f32 rounding boundary, so the two round to the same f32.  The argument needs R only to within a few
-// ulp64 of 1/d, so R comes from v_rcp_f64 and two Newton steps (recip64: the refined reciprocal of the compiler's own
-// f64 division, <= 1 ulp64, the product then within 2^-51 of n/d) instead of a full IEEE division (11 f64 instructions).
-// R is computed once per ray and per instance; each quotient is then cvt + v_mul_f64 + cvt.  Lanes whose ray leaves the guarded
-// range (a zero / denormal / huge direction component, an origin component that is tiny but non-zero)
-// take the reference's literal divisions instead; pbrs_upload_scene checks the node coordinates once.
+// Box test.  geometry/src/bvh.rs:84-99 divides six times per node; IEEE f32 division costs ~11 instructions on gfx950.  With
+// nr = -RN(1 / d) — the correctly rounded reciprocal, once per ray and per instance — the quotient of a numerator n is three
+// instructions on its negation nn = -n:   q0 = RN(nn nr);  e = RN(d q0 + nn), which is exact;  q = RN(e nr + q0),   and q IS
+// RN(n / d), the correctly rounded quotient: for all 2^23 x 2^23 pairs of f32 significands the sequence returns the bits of the
+// IEEE division (tools/microbench/div_exhaustive.hip: 70 368 744 177 664 pairs, no mismatch, 27 s on one MI355X;
+// profiles/r03_div_exhaustive.log), and every operation in it commutes with scaling by powers of two and with the operands' signs
+// as long as nothing overflows or underflows (a zero quotient may come out with the other sign, which no comparison of the box
+// test sees).  Rounds 1 and 2 took the same quotient through f64 — cvt, v_mul_f64 by a refined v_rcp_f64, cvt: three
+// instructions at 4.3 issue cycles each where these are 2.7 each (tools/microbench/issue_rates.hip), and six registers for
+// the reciprocals where these take three.  Lanes whose ray leaves the guarded range (a zero / denormal / huge direction
+// component, an origin component that is tiny but non-zero) take the reference's literal divisions instead;
+// pbrs_upload_scene checks the node coordinates once.
 #pragma once
 #include "shapes.h"
 
@@ -39,7 +41,7 @@
 
 struct RaySpace {
     f3 o, d;
-    double rx, ry, rz;  // rn64(1 / d)
+    f3 nr;  // -RN(1 / d) per component (rays on the division-free test; zero otherwise)
     bool fast;
 };
 // Branch-free (one unsigned compare per range; `&`, not `&&`): six short-circuit branches here cost more than the tests.
@@ -52,30 +54,14 @@ PD uint32_t origin_in_range(float x) {  // zero, or 2^-60 <= |x| <= 2^40
     uint32_t e = u >> 23;
     return ((u == 0u) | (e - (127u - 60u) <= 100u)) ? 1u : 0u;
 }
-// 1 / x for a normal f64 x of moderate exponent (|x| in [2^-40, 2^40] here): v_rcp_f64 is good to about 2^-26, each
-// Newton step r <- r + r (1 - x r) squares the error; after two the result is within one ulp64.
-PD double recip64(double x) {
-#ifdef PBRS_IEEE_RECIP64
-    return 1.0 / x;
-#else
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
-    return r;
-#endif
-}
 PD RaySpace make_space(f3 o, f3 d, bool scene_ok) {
     RaySpace r;
     r.o = o;
     r.d = d;
     r.fast = ((scene_ok ? 1u : 0u) & dir_in_range(d.x) & dir_in_range(d.y) & dir_in_range(d.z) & origin_in_range(o.x) &
               origin_in_range(o.y) & origin_in_range(o.z)) != 0u;
-    r.rx = r.ry = r.rz = 0.0;
-    if (r.fast) {
-        r.rx = recip64((double)d.x);
-        r.ry = recip64((double)d.y);
-        r.rz = recip64((double)d.z);
-    }
+    r.nr = gray(0.0f);
+    if (r.fast) r.nr = mk3(-(1.0f / d.x), -(1.0f / d.y), -(1.0f / d.z));  // IEEE divisions: correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
     return r;
 }
 // The world-space ray of a lane that is inside an instance is not kept anywhere: when the lane comes back out it reads
@@ -98,12 +84,17 @@ PD void leave_instance(const DevScene& S, LaneStack stk, uint32_t moved, RaySpac
         C = reload_world(S, stk);
     }
 }
-PD float qdiv(float n, double r) { return (float)((double)n * r); }
+// RN(n / d) from the NEGATED numerator nn = -n, the denominator and nr = -RN(1 / d): see the head of this file
+PD float qdiv(float nn, float d, float nr) {
+    const float q0 = nn * nr;
+    const float e = __builtin_fmaf(d, q0, nn);
+    return __builtin_fmaf(e, nr, q0);
+}
 // geometry/src/bvh.rs:84-99 (same min/max/NaN conventions as dmath.h::slab_test)
 PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
     if (!R.fast) return slab_test(nmin(n), nmax(n), R.o, R.d, t_max);
-    float t0x = qdiv(n.min[0] - R.o.x, R.rx), t0y = qdiv(n.min[1] - R.o.y, R.ry), t0z = qdiv(n.min[2] - R.o.z, R.rz);
-    float t1x = qdiv(n.max[0] - R.o.x, R.rx), t1y = qdiv(n.max[1] - R.o.y, R.ry), t1z = qdiv(n.max[2] - R.o.z, R.rz);
+    float t0x = qdiv(R.o.x - n.min[0], R.d.x, R.nr.x), t0y = qdiv(R.o.y - n.min[1], R.d.y, R.nr.y), t0z = qdiv(R.o.z - n.min[2], R.d.z, R.nr.z);
+    float t1x = qdiv(R.o.x - n.max[0], R.d.x, R.nr.x), t1y = qdiv(R.o.y - n.max[1], R.d.y, R.nr.y), t1z = qdiv(R.o.z - n.max[2], R.d.z, R.nr.z);
     // Inside the guarded range every quotient is finite, so the SSE / f32::max conventions of the reference reduce
     // to plain min/max (they differ only on NaN operands and on the sign of a zero, which no comparison sees):
     // v_min_f32 / v_max_f32 / v_min3 / v_max3 instead of compare+select chains.
@@ -118,8 +109,8 @@ PD bool slab_rs(const pbrs_node& n, const RaySpace& R, float t_max) {
 // finite extent t the reference's test is t_low <= min(hi_el, t), i.e. this result AND t_low <= t — which is how a closest-hit
 // walk re-evaluates a scanned TLAS leaf at its turn without fetching the box again (ClosestWalkW, FlatScan::run_tlow).
 PD bool slab_rs_tlow(const pbrs_node& n, const RaySpace& R, float& t_low) {
-    float t0x = qdiv(n.min[0] - R.o.x, R.rx), t0y = qdiv(n.min[1] - R.o.y, R.ry), t0z = qdiv(n.min[2] - R.o.z, R.rz);
-    float t1x = qdiv(n.max[0] - R.o.x, R.rx), t1y = qdiv(n.max[1] - R.o.y, R.ry), t1z = qdiv(n.max[2] - R.o.z, R.rz);
+    float t0x = qdiv(R.o.x - n.min[0], R.d.x, R.nr.x), t0y = qdiv(R.o.y - n.min[1], R.d.y, R.nr.y), t0z = qdiv(R.o.z - n.min[2], R.d.z, R.nr.z);
+    float t1x = qdiv(R.o.x - n.max[0], R.d.x, R.nr.x), t1y = qdiv(R.o.y - n.max[1], R.d.y, R.nr.y), t1z = qdiv(R.o.z - n.max[2], R.d.z, R.nr.z);
     float lo_el = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
     float hi_el = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
     t_low = __builtin_fmaxf(lo_el, 0.0f);
@@ -142,7 +133,7 @@ PD uint32_t enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace&
         C.o = oo;
         if (!(origin_in_range(oo.x) & origin_in_range(oo.y) & origin_in_range(oo.z))) {
             C.fast = false;
-            C.rx = C.ry = C.rz = 0.0;
+            C.nr = gray(0.0f);
         }
         return PBRS_SPACE_TRANSLATED;
     }
@@ -236,9 +227,6 @@ struct TriShare {
 struct FlatScan {
     PD static uint32_t pull(uint32_t from, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
     PD static float pull(uint32_t from, float v) { return __uint_as_float(pull(from, __float_as_uint(v))); }
-    PD static double pull(uint32_t from, double v) {
-        return __hiloint2double((int)pull(from, (uint32_t)__double2hiint(v)), (int)pull(from, (uint32_t)__double2loint(v)));
-    }
     // Returns, to each fresh lane, the mask of the leaves whose box its ray R (on the division-free test) passes within
     // t_max; `tested` counts the box tests this lane ran as a helper.  Every lane of the wave calls this together;
     // S.n_flat <= PBRS_FLAT_TLAS_MAX_ANYHIT = 32.
@@ -260,10 +248,8 @@ struct FlatScan {
             const uint32_t owner = pull(r, list);
             RaySpace O;
             O.o = mk3(pull(owner, R.o.x), pull(owner, R.o.y), pull(owner, R.o.z));
-            O.d = gray(0.0f);  // not read by the division-free test
-            O.rx = pull(owner, R.rx);
-            O.ry = pull(owner, R.ry);
-            O.rz = pull(owner, R.rz);
+            O.d = mk3(pull(owner, R.d.x), pull(owner, R.d.y), pull(owner, R.d.z));
+            O.nr = mk3(pull(owner, R.nr.x), pull(owner, R.nr.y), pull(owner, R.nr.z));
             O.fast = true;
             const float ot = pull(owner, t_max);
             bool pass0 = false, pass1 = false;
@@ -297,7 +283,7 @@ struct FlatScan {
         const uint32_t rank = lane_prefix(m);
         const uint32_t list = (uint32_t)__builtin_amdgcn_ds_permute((int)((fresh ? rank : 63u) << 2), (int)lane);
         const uint32_t magic = (65536u + H - 1u) / H;
-        const f3 r32 = mk3((float)R.rx, (float)R.ry, (float)R.rz);  // RN32 of the f64 reciprocals: what the filter is proved on
+        const f3 r32 = -R.nr;  // RN(1 / d): what the filter is proved on
         uint32_t mine = 0;
         for (uint32_t base = 0; base < total; base += 64u) {
             const uint32_t p = base + lane;
@@ -353,10 +339,8 @@ PD uint32_t flat_scan_tlow(const DevScene& S, bool fresh, const RaySpace& R, flo
         const uint32_t owner = FlatScan::pull(r, list);
         RaySpace O;
         O.o = mk3(FlatScan::pull(owner, R.o.x), FlatScan::pull(owner, R.o.y), FlatScan::pull(owner, R.o.z));
-        O.d = gray(0.0f);
-        O.rx = FlatScan::pull(owner, R.rx);
-        O.ry = FlatScan::pull(owner, R.ry);
-        O.rz = FlatScan::pull(owner, R.rz);
+        O.d = mk3(FlatScan::pull(owner, R.d.x), FlatScan::pull(owner, R.d.y), FlatScan::pull(owner, R.d.z));
+        O.nr = mk3(FlatScan::pull(owner, R.nr.x), FlatScan::pull(owner, R.nr.y), FlatScan::pull(owner, R.nr.z));
         O.fast = true;
         bool pass0 = false, pass1 = false;
         if (valid) {
@@ -409,7 +393,7 @@ struct ClosestWalk {
     uint32_t mode;
     typename GridSel<GRID>::type G;  // GRID walks: the ray on the grid of the mesh it is in
     PBRS_TP_FIELDS
-    PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }  // GRID walks: not state (exact_space recomputes them)
+    PD void forget_reciprocals() { C.nr = gray(0.0f); }  // GRID walks: not state (exact_space recomputes them)
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         C = make_space(o, d, S.fast_slab != 0);
@@ -844,7 +828,7 @@ struct AnyWalk {
     uint32_t mode;
     typename GridSel<GRID>::type G;
     PBRS_TP_FIELDS
-    PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
+    PD void forget_reciprocals() { C.nr = gray(0.0f); }
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         C = make_space(o, d, S.fast_slab != 0);
@@ -1194,6 +1178,16 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     using B::inst_info; using B::leaf_a; using B::leaf_end; using B::sp; using B::blas_base; using B::cand; using B::in_blas; using B::moved; using B::mode;
     typename WRaySel<ARITY>::type W;
     uint32_t cur;  // wide node to take next (the nearest survivor of the last node step), or PBRS_WREF_NONE
+    // the lane's space with its reciprocals, for the reference's own test: the wide and pair walks keep them (as RN(1 / d)) for their filter
+    PD RaySpace exact_w() const {
+        if constexpr (ARITY == 1u) {
+            return exact_space(C);
+        } else {
+            RaySpace E = C;
+            E.nr = -W.r32;
+            return E;
+        }
+    }
     // A BLAS leaf held UNVERIFIED is (leaf_a = its node index, leaf_end = PBRS_LEAF_UNVERIFIED); the scanned TLAS leaf about to be
     // entered travels in leaf_a too.  The lane's column of the block's entry-distance table sits after the stack rows:
     // row DevScene::wide_cap + k for scanned leaf k.  A wide walk is never below a TLAS entry (the TLAS is scanned): blas_base = 0.
@@ -1220,7 +1214,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     }
     // The f64 reciprocals are not state of a wide walk (exact_space): dropping them at the end of every loop round keeps six
     // registers from living across it (the shared scan reads them from every lane of the wave, fresh or not).
-    PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
+    PD void forget_reciprocals() { C.nr = gray(0.0f); }
     // The node step over compressed records, written for the instruction count of its common path (one load, one filter, selects):
     // everything rare — the next scanned TLAS leaf, the end of a mesh — sits behind the one test for an empty stack.
     PD void node_step_c(const DevScene& S, LaneStack stk) {
@@ -1400,7 +1394,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
                 return;
             }
             // the root against the incoming extent (blas.rs:441 at the first pop), the reference's test; then lt = mt (:468)
-            if (!slab_rs(load_node(S.nodes + in.blas_root), exact_space(C), lt)) {
+            if (!slab_rs(load_node(S.nodes + in.blas_root), exact_w(), lt)) {
                 mode = B::exit_mode();
                 return;
             }
@@ -1421,7 +1415,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             const pbrs_node node = load_node(S.nodes + leaf_a);
             leaf_a = node.a;
             leaf_end = node.a;
-            if (slab_rs(node, exact_space(C), lt)) {
+            if (slab_rs(node, exact_w(), lt)) {
                 PBRS_TP(4);
                 leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
                 if (leaf_end == leaf_a) lt = mt;  // an empty leaf still runs blas.rs:468
@@ -1491,6 +1485,15 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
     using B::occluded; using B::moved; using B::mode;
     typename WRaySel<ARITY>::type W;
     uint32_t cur;
+    PD RaySpace exact_w() const {  // see ClosestWalkW::exact_w
+        if constexpr (ARITY == 1u) {
+            return exact_space(C);
+        } else {
+            RaySpace E = C;
+            E.nr = -W.r32;
+            return E;
+        }
+    }
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         B::start(S, o, d, tmax, stk);
@@ -1508,7 +1511,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
         leaf_end = PBRS_LEAF_UNVERIFIED;
         mode = PBRS_WALK_LEAF;
     }
-    PD void forget_reciprocals() { C.rx = C.ry = C.rz = 0.0; }
+    PD void forget_reciprocals() { C.nr = gray(0.0f); }
     PD void node_step_c(const DevScene& S, LaneStack stk) {  // see ClosestWalkW::node_step_c
         uint32_t e = cur;
         if (e == PBRS_WREF_NONE) {
@@ -1670,7 +1673,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             // The root's own test is not needed for the answer (any hit: inner-node tests only prune), but it is one test that ends most
             // misses here — also behind an identity transform, where the scan has tested the same box: skipping it there was
             // measured slower (C4 k_shadow 238.5 -> 241.5 ms per frame; the first wide node's four tests cost more than this one)
-            if (!slab_rs(load_node(S.nodes + in.blas_root), exact_space(C), t_max)) {
+            if (!slab_rs(load_node(S.nodes + in.blas_root), exact_w(), t_max)) {
                 mode = B::exit_mode();
                 return;
             }
@@ -1686,7 +1689,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             PBRS_TP(3);
             const pbrs_node node = load_node(S.nodes + leaf_a);
             leaf_a = node.a;
-            leaf_end = slab_rs(node, exact_space(C), t_max) ? node.a + (node.b & ~PBRS_LEAF_FLAG) : node.a;
+            leaf_end = slab_rs(node, exact_w(), t_max) ? node.a + (node.b & ~PBRS_LEAF_FLAG) : node.a;
             if (leaf_end != leaf_a) PBRS_TP(4);
             if (leaf_end == leaf_a) mode = after_leaf();
         }

@@ -50,7 +50,7 @@ struct WideRay {
     f3 r32;       // RN32 of the f64 reciprocals of the direction
     uint32_t nb;  // byte offsets of the planes met first on each axis, one per byte: axis * 16 (+ 48 where the direction is negative)
     PD void set(const RaySpace& C) {
-        r32 = mk3((float)C.rx, (float)C.ry, (float)C.rz);
+        r32 = -C.nr;
         nb = (C.d.x > 0.0f ? 0u : 48u) | (C.d.y > 0.0f ? 16u : 64u) << 8 | (C.d.z > 0.0f ? 32u : 80u) << 16;
     }
     PD uint32_t nx() const { return nb & 0xffu; }
@@ -58,14 +58,12 @@ struct WideRay {
     PD uint32_t nz() const { return nb >> 16; }
 };
 
-// The reference's test needs the f64 reciprocals (slab_rs): a wide walk asks for it a few times per ray (a mesh's root, the
-// leaves that come up), so it does not keep them in registers between node steps — recip64 is a pure function of the
-// direction, recomputing it gives the bits make_space had.
+// The reference's test needs the reciprocals (slab_rs): a wide walk asks for it a few times per ray (a mesh's root, the leaves
+// that come up) and does not keep them as walk state between node steps (forget_reciprocals) — a correctly rounded division is a
+// pure function of the direction, recomputing it gives the bits make_space had.
 PD RaySpace exact_space(const RaySpace& C) {
     RaySpace E = C;
-    E.rx = recip64((double)C.d.x);
-    E.ry = recip64((double)C.d.y);
-    E.rz = recip64((double)C.d.z);
+    E.nr = mk3(-(1.0f / C.d.x), -(1.0f / C.d.y), -(1.0f / C.d.z));
     return E;
 }
 
@@ -153,7 +151,7 @@ struct PairRay {
     f3 r32;               // RN32 of the f64 reciprocals of the direction
     uint32_t nx, ny, nz;  // byte offset of the planes met first on that axis within the node: axis * 8 (+ 24 where the direction is not positive)
     PD void set(const RaySpace& C) {
-        r32 = mk3((float)C.rx, (float)C.ry, (float)C.rz);
+        r32 = -C.nr;
         nx = C.d.x > 0.0f ? 0u : 24u;
         ny = C.d.y > 0.0f ? 8u : 32u;
         nz = C.d.z > 0.0f ? 16u : 40u;
