@@ -31,7 +31,7 @@ struct DevScene {
     uint32_t n_area, n_delta;
     float env[3];
     uint32_t has_env;
-    uint32_t fast_slab;  // node coordinates are inside the range the f64-reciprocal box test is exact for (traverse.h)
+    uint32_t fast_slab;  // node coordinates are inside the range the division-free box test is exact for (traverse.h)
     // Small TLAS (PBRS_FLAT_TLAS_MIN..MAX instances): its leaves alone, in pre-order = the order the tree walk reaches them.
     // A box inside a box that a ray misses is missed too (each slab bound is a correctly rounded, hence monotonic,
     // function of the box coordinate), so testing the leaf boxes in this order — each against the t_max of its turn —

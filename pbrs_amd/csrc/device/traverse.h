@@ -366,7 +366,7 @@ PD uint32_t flat_scan_tlow(const DevScene& S, bool fresh, const RaySpace& R, flo
 // GRID walks: the binary walks below with the box tests of a mesh's nodes made on the nodes' compressed records (wide.h: one
 // 16-byte load and a filter instead of two loads and the exact test) for rays on the division-free test.  A leaf whose record
 // passes is held unverified until the shared leaf step gives it the reference's own test; the box of a scanned TLAS leaf is
-// tested, exactly, at the boundary step that would enter it; the f64 reciprocals are recomputed for those few exact tests
+// tested, exactly, at the boundary step that would enter it; the reciprocals are recomputed for those few exact tests
 // (exact_space) instead of living in six registers.  Only for scenes whose TLAS is scanned (DevScene::n_flat != 0).
 template <bool GRID>
 struct GridSel {
@@ -1212,7 +1212,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
         leaf_end = PBRS_LEAF_UNVERIFIED;
         mode = PBRS_WALK_LEAF;
     }
-    // The f64 reciprocals are not state of a wide walk (exact_space): dropping them at the end of every loop round keeps six
+    // The space's own reciprocals are not state of a wide walk (exact_w): dropping them at the end of every loop round keeps three
     // registers from living across it (the shared scan reads them from every lane of the wave, fresh or not).
     PD void forget_reciprocals() { C.nr = gray(0.0f); }
     // The node step over compressed records, written for the instruction count of its common path (one load, one filter, selects):

@@ -13,7 +13,7 @@
 // child, where it is a leaf) of an inner node X, in left-first order, tested together with pn_slab_filter (include/pbrs_numeric.h:
 // f32 products by the rounded reciprocals, bounds widened by 2^-21 — proved and tested never to reject what the reference
 // accepts); the children that pass are visited in the reference's order (three split axes per wide node: X's and its two
-// children's).  A leaf that comes up gets the reference's exact test (slab_rs, f64 reciprocals) at ITS turn, with the best hit
+// children's).  A leaf that comes up gets the reference's exact test (slab_rs) at ITS turn, with the best hit
 // of that moment, before its triangles are tested (closest hit), or once one of its triangles has passed (any hit).  The
 // sequence of (leaf, extent) pairs whose triangles are tested — hence every hit, every tie-break and the final result — is the
 // reference's.  Measured on C4's terrain (tools/trav_stats): 54 box tests in 54 dependent steps per bounce ray become 54
@@ -47,7 +47,7 @@ struct pbrs_wnode {
 // slots 0, 1: the children of X's left child (or that child itself in slot 0, where it is a leaf); slots 2, 3: of its right child
 
 struct WideRay {
-    f3 r32;       // RN32 of the f64 reciprocals of the direction
+    f3 r32;       // RN(1 / d) per component: the correctly rounded reciprocals of the direction (-RaySpace::nr)
     uint32_t nb;  // byte offsets of the planes met first on each axis, one per byte: axis * 16 (+ 48 where the direction is negative)
     PD void set(const RaySpace& C) {
         r32 = -C.nr;
@@ -148,7 +148,7 @@ struct pbrs_pnode {     // 64 bytes = half an L2 line
     uint32_t pad;
 };
 struct PairRay {
-    f3 r32;               // RN32 of the f64 reciprocals of the direction
+    f3 r32;               // RN(1 / d) per component (-RaySpace::nr)
     uint32_t nx, ny, nz;  // byte offset of the planes met first on that axis within the node: axis * 8 (+ 24 where the direction is not positive)
     PD void set(const RaySpace& C) {
         r32 = -C.nr;

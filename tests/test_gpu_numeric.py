@@ -46,10 +46,11 @@ def test_denormal_division_is_not_flushed(gpu_ctx):
 
 
 def test_box_test_quotient_is_the_correctly_rounded_division(gpu_ctx):
-    """device/traverse.h: (float)((double)n * R), R = v_rcp_f64 + two Newton steps, must be n / d bit for bit wherever the
-    division-free box test is used (|d| in [2^-40, 2^40], n zero or of moderate size): random operands, then operands
-    built to sit next to f32 rounding boundaries (n / d within 2^-47 of a midpoint between two neighbouring floats, the
-    closest a ratio of two 24-bit significands can get), where any error of R beyond a few ulp64 would flip the result."""
+    """device/traverse.h: q0 = nn nr; e = fma(d, q0, nn); q = fma(e, nr, q0) on nn = -n, nr = -RN(1 / d) must be n / d bit for bit
+    wherever the division-free box test is used (|d| in [2^-40, 2^40], n zero or of moderate size).  The proof is the exhaustive
+    run of tools/microbench/div_exhaustive.hip over all 2^46 significand pairs (profiles/r03_div_exhaustive.log); this test keeps
+    the kernel honest about it on random operands and on operands built to sit next to f32 rounding boundaries (n / d within
+    2^-47 of a midpoint between two neighbouring floats, the closest a ratio of two 24-bit significands can get)."""
     n = (RS.standard_normal(N) * np.exp(RS.uniform(-30, 30, N))).astype(np.float32)
     d = (np.where(RS.rand(N) < 0.5, -1.0, 1.0) * np.exp(RS.uniform(np.log(2.0 ** -40), np.log(2.0 ** 40), N))).astype(np.float32)
     n[:4] = [0.0, -0.0, 1.0, 3.0]
