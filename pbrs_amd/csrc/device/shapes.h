@@ -380,6 +380,12 @@ PD pbrs_node load_node(const pbrs_node* p) {
     n.max[0] = b.x; n.max[1] = b.y; n.max[2] = b.z; n.b = __float_as_uint(b.w);
     return n;
 }
+// Node i of an array addressed with a 32-bit byte offset from a wave-uniform base: one 32-bit shift for the address where the
+// pointer form takes two 64-bit instructions (pbrs_upload_scene keeps DevScene::nodes below 4 GiB)
+PD pbrs_node load_node_at(const pbrs_node* base, uint32_t i) {
+    const char* p = reinterpret_cast<const char*>(base) + (uint32_t)(i * (uint32_t)sizeof(pbrs_node));
+    return load_node(reinterpret_cast<const pbrs_node*>(p));
+}
 PD pbrs_tri_verts load_tri(const pbrs_tri_verts* p) {
     const float4* q = reinterpret_cast<const float4*>(p);
     float4 a = q[0], b = q[1], c = q[2];

@@ -499,7 +499,7 @@ struct ClosestWalk {
                 else CNT(tlas_nodes);
             }
         }
-        const pbrs_node node = load_node(S.nodes + ni);
+        const pbrs_node node = load_node_at(S.nodes, ni);
         PBRS_TP(1);
         if (!slab_rs(node, C, lt)) {
             PBRS_TP(2);
@@ -571,7 +571,7 @@ struct ClosestWalk {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
         }
-        const pbrs_node node = load_node(S.nodes + ni);
+        const pbrs_node node = load_node_at(S.nodes, ni);
         PBRS_TP(1);
         RaySpace F = C;
         F.fast = true;  // known here: this copy of the box test carries no division path
@@ -908,7 +908,7 @@ struct AnyWalk {
                 return;
             }
         }
-        const pbrs_node node = load_node(S.nodes + ni);
+        const pbrs_node node = load_node_at(S.nodes, ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
@@ -968,7 +968,7 @@ struct AnyWalk {
         }
         PBRS_TP(0);
         const uint32_t ni = stk.get(--sp);
-        const pbrs_node node = load_node(S.nodes + ni);
+        const pbrs_node node = load_node_at(S.nodes, ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);

@@ -1148,6 +1148,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         nodes.insert(nodes.end(), d->blas_nodes, d->blas_nodes + d->n_blas_nodes);
         for (size_t i = blas_off; i < nodes.size(); ++i)
             if (!(nodes[i].b & PBRS_LEAF_FLAG)) nodes[i].a += (uint32_t)blas_off;  // right child; the left one is i + 1
+        if (nodes.size() * sizeof(pbrs_node) >= (1ull << 32)) return fail(c, PBRS_E_LIMIT, "too many BVH nodes (the walks address them with 32-bit byte offsets)");
         if ((rc = upload(c, nodes.data(), nodes.size(), &S.nodes))) return rc;
         std::vector<pbrs_instance> inst(d->instances, d->instances + d->n_instances);
         // Shading classes: one per distinct lobe signature among the materials (class 0: no lobes — emitters — and misses)
