@@ -1208,7 +1208,7 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
     }
     PD uint32_t after_leaf() const { return sp == 0 ? B::exit_mode() : PBRS_WALK_NODE; }
     PD void hold_leaf(uint32_t ref) {
-        leaf_a = ref & ~PBRS_WREF_LEAF;
+        leaf_a = ref & PBRS_WREF_INDEX;
         leaf_end = PBRS_LEAF_UNVERIFIED;
         mode = PBRS_WALK_LEAF;
     }
@@ -1507,7 +1507,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
     }
     PD uint32_t after_leaf() const { return sp == 0 ? B::exit_mode() : PBRS_WALK_NODE; }
     PD void hold_leaf(uint32_t ref) {
-        leaf_a = ref & ~PBRS_WREF_LEAF;
+        leaf_a = ref & PBRS_WREF_INDEX;
         leaf_end = PBRS_LEAF_UNVERIFIED;
         mode = PBRS_WALK_LEAF;
     }

@@ -30,8 +30,12 @@ struct pbrs_wnode {
     float lo[3][4];     // [axis][slot]: min planes   (bytes   0 ..  47)
     float hi[3][4];     // [axis][slot]: max planes   (bytes  48 ..  95)
     uint32_t child[4];  // PBRS_WREF_LEAF | index of the reference's leaf node in DevScene::nodes; else index of a wide node; PBRS_WREF_NONE
-    uint32_t info;      // bits 0-1: split axis of X; 2-3: of X's left child; 4-5: of its right child; bits 8-11: slots in use
-    uint32_t pad[3];
+                        // in a slot not in use (its box is inverted — lo = 2^60, hi = -2^60 — and fails the filter for every ray of the
+                        // guarded range, without an overflow).  Slots 0 and 2 are always in use and carry the three split axes above
+                        // the index (PBRS_WREF_AXIS_SHIFT): child[0] bits 27-28 X's, bits 29-30 its left child's; child[2] bits 27-28 its
+                        // right child's — a node step reads seven vectors, not eight (a load whose lanes name different lines costs
+                        // the L1 a cycle per lane whatever its width: C4 k_shadow 151 accesses per ray)
+    uint32_t pad[4];
 };
 #ifndef PBRS_WIDE_STACK_MAX
 #define PBRS_WIDE_STACK_MAX 16  // LDS stack entries per lane of the wide-walk kernels (C4's terrain: 12 at most over a frame's rays)
@@ -44,6 +48,9 @@ struct pbrs_wnode {
 #endif
 #define PBRS_WREF_LEAF 0x80000000u
 #define PBRS_WREF_NONE 0xffffffffu
+#define PBRS_WREF_INDEX 0x07ffffffu  // a leaf's index in DevScene::nodes (below 2^27: the node array is addressed with 32-bit byte offsets); a wide
+#define PBRS_WREF_AXIS_SHIFT 27      // node's index loses the bits above it in `index * sizeof(pbrs_wnode)` (below 2^25 for the same reason)
+#define PBRS_WIDE_UNUSED_PLANE 1152921504606846976.0f /* 2^60 */
 // slots 0, 1: the children of X's left child (or that child itself in slot 0, where it is a leaf); slots 2, 3: of its right child
 
 struct WideRay {
@@ -69,8 +76,10 @@ PD RaySpace exact_space(const RaySpace& C) {
 
 struct WideTest {
     uint32_t pass;  // bit s: slot s passed the filter
-    uint32_t child[4];
-    uint32_t info;
+    uint32_t child[4];  // as stored: axis bits included
+    PD int axis_x() const { return (int)((child[0] >> PBRS_WREF_AXIS_SHIFT) & 3u); }
+    PD int axis_left() const { return (int)((child[0] >> (PBRS_WREF_AXIS_SHIFT + 2)) & 3u); }
+    PD int axis_right() const { return (int)((child[2] >> PBRS_WREF_AXIS_SHIFT) & 3u); }
 };
 // The four slots of wide node `wi` against the ray (C: origin; W: reciprocals, plane choice) within `t_max`.  One uniform base
 // and 32-bit byte offsets per lane (wide nodes are indexed below 2^24: pbrs_upload_scene).
@@ -83,7 +92,6 @@ PD WideTest wide_test(const pbrs_wnode* nodes, uint32_t wi, const RaySpace& C, c
                  fz = *reinterpret_cast<const float4*>(base + (at + (112u - W.nz())));
     const uint4 ch = *reinterpret_cast<const uint4*>(base + (at + 96u));
     WideTest t;
-    t.info = *reinterpret_cast<const uint32_t*>(base + (at + 112u));
     t.child[0] = ch.x, t.child[1] = ch.y, t.child[2] = ch.z, t.child[3] = ch.w;
     // (scalar operations: the packed forms v_pk_add_f32 / v_pk_mul_f32 for two slots at a time were measured slower — C4 k_shadow
     // 236 -> 292 ms per frame, the register allocator spilling the ray's origin around them)
@@ -91,7 +99,10 @@ PD WideTest wide_test(const pbrs_wnode* nodes, uint32_t wi, const RaySpace& C, c
     const uint32_t p1 = pn_slab_filter(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, C.o.x, C.o.y, C.o.z, W.r32.x, W.r32.y, W.r32.z, t_max) ? 2u : 0u;
     const uint32_t p2 = pn_slab_filter(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, C.o.x, C.o.y, C.o.z, W.r32.x, W.r32.y, W.r32.z, t_max) ? 4u : 0u;
     const uint32_t p3 = pn_slab_filter(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, C.o.x, C.o.y, C.o.z, W.r32.x, W.r32.y, W.r32.z, t_max) ? 8u : 0u;
-    t.pass = (p0 | p1 | p2 | p3) & (t.info >> 8);
+    t.pass = p0 | p1 | p2 | p3;  // (a slot not in use never passes: its box is inverted)
+    // the links are wanted here, with the planes: left to itself the compiler sinks their load behind the test of `pass` — a second
+    // memory latency on the dependent chain of every node step that goes on (C4 k_shadow 219 -> 228 ms per frame)
+    asm volatile("" : "+v"(t.child[0]), "+v"(t.child[1]), "+v"(t.child[2]), "+v"(t.child[3]));
     return t;
 }
 
@@ -102,9 +113,9 @@ struct WideOrder {
 };
 // The reference's order (blas.rs:456-466: the left child first iff `ray.dir[axis] > 0`, at X and at each of its children)
 PD WideOrder wide_order(const WideTest& t, f3 d) {
-    const bool sx = !(comp(d, (int)(t.info & 3u)) > 0.0f);         // X: its right child's side first
-    const bool sa = !(comp(d, (int)((t.info >> 2) & 3u)) > 0.0f);  // within X's left child
-    const bool sb = !(comp(d, (int)((t.info >> 4) & 3u)) > 0.0f);  // within X's right child
+    const bool sx = !(comp(d, t.axis_x()) > 0.0f);         // X: its right child's side first
+    const bool sa = !(comp(d, t.axis_left()) > 0.0f);  // within X's left child
+    const bool sb = !(comp(d, t.axis_right()) > 0.0f);  // within X's right child
     const uint32_t q0 = t.pass & 1u, q1 = (t.pass >> 1) & 1u, q2 = (t.pass >> 2) & 1u, q3 = (t.pass >> 3) & 1u;
     const uint32_t a0 = sa ? t.child[1] : t.child[0], a1 = sa ? t.child[0] : t.child[1], qa0 = sa ? q1 : q0, qa1 = sa ? q0 : q1;
     const uint32_t b0 = sb ? t.child[3] : t.child[2], b1 = sb ? t.child[2] : t.child[3], qb0 = sb ? q3 : q2, qb1 = sb ? q2 : q3;
@@ -115,7 +126,7 @@ PD WideOrder wide_order(const WideTest& t, f3 d) {
 }
 // Any order gives an any-hit walk the same answer; the side of X the ray enters first goes first (finds an occluder sooner)
 PD WideOrder wide_order_any(const WideTest& t, f3 d) {
-    const bool sx = !(comp(d, (int)(t.info & 3u)) > 0.0f);
+    const bool sx = !(comp(d, t.axis_x()) > 0.0f);
     const uint32_t q0 = t.pass & 1u, q1 = (t.pass >> 1) & 1u, q2 = (t.pass >> 2) & 1u, q3 = (t.pass >> 3) & 1u;
     WideOrder o;
     o.r[0] = sx ? t.child[3] : t.child[0], o.r[1] = sx ? t.child[2] : t.child[1], o.r[2] = sx ? t.child[1] : t.child[2], o.r[3] = sx ? t.child[0] : t.child[3];

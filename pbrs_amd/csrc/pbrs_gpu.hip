@@ -295,7 +295,10 @@ uint32_t build_wide(const std::vector<pbrs_node>& nodes, uint32_t x, std::vector
     pbrs_wnode w{};
     for (uint32_t k = 0; k < 4; ++k) {
         w.child[k] = PBRS_WREF_NONE;
-        if (!((used >> k) & 1u)) continue;
+        if (!((used >> k) & 1u)) {  // never passes the filter (device/wide.h)
+            for (int a = 0; a < 3; ++a) w.lo[a][k] = PBRS_WIDE_UNUSED_PLANE, w.hi[a][k] = -PBRS_WIDE_UNUSED_PLANE;
+            continue;
+        }
         const pbrs_node& n = nodes[slot_node[k]];
         for (int a = 0; a < 3; ++a) {
             w.lo[a][k] = n.min[a];
@@ -303,7 +306,8 @@ uint32_t build_wide(const std::vector<pbrs_node>& nodes, uint32_t x, std::vector
         }
         w.child[k] = (n.b & PBRS_LEAF_FLAG) ? (PBRS_WREF_LEAF | slot_node[k]) : build_wide(nodes, slot_node[k], out, level + 1u, levels);
     }
-    w.info = info | used << 8;
+    w.child[0] |= (info & 15u) << PBRS_WREF_AXIS_SHIFT;  // slots 0 and 2 are always in use
+    w.child[2] |= ((info >> 4) & 3u) << PBRS_WREF_AXIS_SHIFT;
     out[me] = w;
     return me;
 }

@@ -21,8 +21,39 @@ static int exact(const float* bmin, const float* bmax, const float* o, const flo
     }
     return mx(lo, 0.0f) <= mn(hi, t_max);
 }
+/* A slot of a four-wide node that is not in use holds the inverted box lo = 2^60, hi = -2^60 (device/wide.h): the filter must
+ * refuse it for every ray of the guarded range — direction components normal within 2^+-40, origin zero or within
+ * [2^-60, 2^40], any extent — the extremes of the exponents included.  Prints: cases, passes (must be 0). */
+static float guarded(int lo_exp, int hi_exp, int allow_zero) {
+    const uint32_t k = u32() % 8u;
+    if (allow_zero && k == 0u) return (u32() & 1u) ? 0.0f : -0.0f;
+    const int e = k == 1u ? lo_exp : k == 2u ? hi_exp : lo_exp + (int)(u32() % (uint32_t)(hi_exp - lo_exp + 1));
+    float m = k == 3u ? 1.0f : 1.0f + uni();
+    if (e == hi_exp) m = 1.0f;
+    return ((u32() & 1u) ? -1.0f : 1.0f) * ldexpf(m, e);
+}
+static int unused_slots(long n) {
+    const float plane = 1152921504606846976.0f; /* PBRS_WIDE_UNUSED_PLANE */
+    long passes = 0;
+    for (long i = 0; i < n; ++i) {
+        float o[3], d[3], r[3], nr[3], fr[3];
+        for (int a = 0; a < 3; ++a) {
+            o[a] = guarded(-60, 40, 1);
+            d[a] = guarded(-40, 40, 0);
+            r[a] = (float)(1.0 / (double)d[a]);
+            nr[a] = d[a] > 0.0f ? plane : -plane;
+            fr[a] = d[a] > 0.0f ? -plane : plane;
+        }
+        const uint32_t k = u32() % 4u;
+        const float t_max = k == 0u ? INFINITY : k == 1u ? 0.0f : k == 2u ? 3.4028234663852886e38f : ldexpf(1.0f + uni(), (int)(u32() % 200u) - 100);
+        passes += pn_slab_filter(nr[0], nr[1], nr[2], fr[0], fr[1], fr[2], o[0], o[1], o[2], r[0], r[1], r[2], t_max) ? 1 : 0;
+    }
+    printf("%ld %ld\n", n, passes);
+    return passes != 0;
+}
 int main(int argc, char** argv) {
     long n = argc > 1 ? atol(argv[1]) : 1000000;
+    if (argc > 2) return unused_slots(n);
     long passes = 0, fpasses = 0, bad = 0;
     for (long i = 0; i < n; ++i) {
         float bmin[3], bmax[3], o[3], d[3], t_max;
