@@ -284,9 +284,11 @@ struct Bsdf {
     const uint32_t* hit_lobe;
     const float* hit_albedo;
     bool lam;  // every lobe is a Lambertian DiffuseReflect and a material has at most one (see bxdf_eval)
+    f3 a0;     // ... whose colour is read once per vertex then (k_shade), not at each of the five places that ask for it
     const FourierView* fourier;  // the scene's Fourier tables, or nullptr in kernels without the lobe (see bxdf_eval)
     PD const pbrs_bxdf& lobe(uint32_t k) const { return lobes[hit_lobe ? hit_lobe[k * 256u] : k]; }
     PD f3 albedo_at(uint32_t k) const {
+        if (lam) return a0;
         if (hit_albedo) return mk3(hit_albedo[(3u * k) * 256u], hit_albedo[(3u * k + 1u) * 256u], hit_albedo[(3u * k + 2u) * 256u]);
         return ld3(lobes[k].albedo);
     }
@@ -303,6 +305,7 @@ PD Bsdf bsdf_new_frame(const Isect& is, const pbrs_bxdf* lobes, uint32_t n) {  /
     b.hit_lobe = nullptr;
     b.hit_albedo = nullptr;
     b.lam = false;
+    b.a0 = gray(0.0f);
     b.fourier = nullptr;
     return b;
 }

@@ -797,6 +797,7 @@ __global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : 
 #endif
             Bsdf bs = bsdf_new_frame(is, S.bxdfs + mat->first_bxdf, mat->n_bxdfs);
             bs.lam = (SPEC & PBRS_SHADE_LAMBERT) != 0u;
+            if ((SPEC & PBRS_SHADE_LAMBERT) && mat->n_bxdfs) bs.a0 = ld3(S.bxdfs[mat->first_bxdf].albedo);
             const FourierView fourier_view{S.fourier, S.tex_floats, S.tex_words, (SPEC & PBRS_SHADE_FOURIER_ONLY) ? s_fourier_ak + threadIdx.x : nullptr,
                                            (SPEC & PBRS_SHADE_FOURIER_ONLY) ? PBRS_FOURIER_AK_ROWS : 0u, (SPEC & PBRS_SHADE_FOURIER_ONLY) != 0u};
             bs.fourier = (SPEC & PBRS_SHADE_FOURIER) ? &fourier_view : nullptr;
