@@ -389,6 +389,10 @@ PD pbrs_node load_node_at(const pbrs_node* base, uint32_t i) {
 PD pbrs_tri_verts load_tri(const pbrs_tri_verts* p) {
     const float4* q = reinterpret_cast<const float4*>(p);
     float4 a = q[0], b = q[1], c = q[2];
+    // three 16-byte loads, issued together: left to itself the compiler narrows them to what each stage of the test reads — five
+    // loads (a lane's load costs the L1 a cycle whatever its width), the third vertex fetched behind the test of t, a second
+    // memory latency for every triangle whose plane the ray meets
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
     pbrs_tri_verts t;
     t.p0[0] = a.x; t.p0[1] = a.y; t.p0[2] = a.z; t.nx = a.w;
     t.p1[0] = b.x; t.p1[1] = b.y; t.p1[2] = b.z; t.ny = b.w;
