@@ -123,13 +123,25 @@ PD bool slab_rs_tlow(const pbrs_node& n, const RaySpace& R, float& t_low) {
 // is finite and non-zero (1*x + 0*y + 0*z + 0*w = x exactly), which is what W.fast plus a non-zero
 // origin guarantee; anything else takes the literal products.
 // Returns PBRS_SPACE_*: what became of the lane's space.
-PD uint32_t enter_instance(const DevScene& S, const pbrs_instance& in, RaySpace& C, bool need_slab, LaneStack stk) {
-    if ((in.flags & PBRS_INSTANCE_IDENTITY) && C.fast && C.o.x != 0.0f && C.o.y != 0.0f && C.o.z != 0.0f) return PBRS_SPACE_WORLD;
+// What a walk reads of an instance besides its matrix, fetched as two loads issued together before the first branch on any of
+// them: the compiler otherwise leaves each field where it is first read — flags, then (behind the branch on them) the BLAS root —
+// one memory latency after the other on a step every ray takes.
+struct InstHead {
+    uint32_t flags, blas_root, mesh_flags, wide_root;
+};
+PD InstHead load_inst_head(const pbrs_instance& in) {
+    uint32_t f = in.flags;
+    uint4 r = *reinterpret_cast<const uint4*>(&in.blas_root);  // blas_root, mesh_flags, pad[0], pad[1] (the wide root): bytes 112 .. 127
+    asm volatile("" : "+v"(f), "+v"(r.x), "+v"(r.y), "+v"(r.w));
+    return {f, r.x, r.y, r.w};
+}
+PD uint32_t enter_instance(const DevScene& S, const pbrs_instance& in, uint32_t in_flags, RaySpace& C, bool need_slab, LaneStack stk) {
+    if ((in_flags & PBRS_INSTANCE_IDENTITY) && C.fast && C.o.x != 0.0f && C.o.y != 0.0f && C.o.z != 0.0f) return PBRS_SPACE_WORLD;
     f3 oo = xf_apply(in.inv, C.o, 1.0f);
     // A pure translation (the 3x3 part of `inverse` bit-exactly the identity, flagged at upload): the Mat4 product
     // returns the direction's own bits — 1*x + 0*y + 0*z + t*0 with x finite and non-zero, which C.fast guarantees — so
     // the reciprocals stay; only the origin moves (and must stay inside the guarded range).
-    if (need_slab && (in.flags & PBRS_INSTANCE_TRANSLATION) && C.fast) {
+    if (need_slab && (in_flags & PBRS_INSTANCE_TRANSLATION) && C.fast) {
         C.o = oo;
         if (!(origin_in_range(oo.x) & origin_in_range(oo.y) & origin_in_range(oo.z))) {
             C.fast = false;
@@ -662,15 +674,16 @@ struct ClosestWalk {
             analytic_visit(S, in, kind, cnt);  // back at the TLAS already
             return;
         }
-        const uint32_t space = enter_instance(S, in, C, kind == PBRS_SHAPE_MESH, stk);
+        const InstHead H = load_inst_head(in);
+        const uint32_t space = enter_instance(S, in, H.flags, C, kind == PBRS_SHAPE_MESH, stk);
         moved = space != PBRS_SPACE_WORLD;
         in_blas = true;
         blas_base = sp;
         lt = t_max;
         mt = pn_inf();
         if (kind == PBRS_SHAPE_MESH) {
-            inst_info = kind | (in.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
-            stk.put(sp++, in.blas_root);
+            inst_info = kind | (H.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
+            stk.put(sp++, H.blas_root);
             if constexpr (GRID) {
                 // onto the grid of this mesh; a ray too far from it walks the mesh's full nodes with the literal divisions (always
                 // the reference's test; it stays on them until a boundary step rebuilds its space)
@@ -679,8 +692,8 @@ struct ClosestWalk {
         } else if (kind == PBRS_SHAPE_TRIANGLE) {
             // IsolatedTriangle (simple.rs:417-426): one triangle record, no boxes, no shading frame
             inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
-            leaf_a = in.blas_root;
-            leaf_end = in.blas_root + 1u;
+            leaf_a = H.blas_root;
+            leaf_end = H.blas_root + 1u;
             mode = PBRS_WALK_LEAF;
         }
     }
@@ -1013,19 +1026,20 @@ struct AnyWalk {
             analytic_visit(S, in, cnt);  // Instance::occludes in one go; back at the TLAS, or occluded
             return;
         }
-        const uint32_t space = enter_instance(S, in, C, inst_kind == PBRS_SHAPE_MESH, stk);
+        const InstHead H = load_inst_head(in);
+        const uint32_t space = enter_instance(S, in, H.flags, C, inst_kind == PBRS_SHAPE_MESH, stk);
         moved = space != PBRS_SPACE_WORLD;
         in_blas = true;
         blas_base = sp;
         if (inst_kind == PBRS_SHAPE_MESH) {
             if (space == PBRS_SPACE_TRANSLATED) inst_kind |= 0x100u;  // only meshes: the tests below read the kind before or mask it
-            stk.put(sp++, in.blas_root);
+            stk.put(sp++, H.blas_root);
             if constexpr (GRID) {
                 if (C.fast && !G.set(C, S.cframes[leaf_a])) C.fast = false;  // (ClosestWalk::xfer_step)
             }
         } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {  // IsolatedTriangle::occludes (simple.rs:428-433): its triangle record
-            leaf_a = in.blas_root;
-            leaf_end = in.blas_root + 1u;
+            leaf_a = H.blas_root;
+            leaf_end = H.blas_root + 1u;
             mode = PBRS_WALK_LEAF;
         }
     }
@@ -1157,8 +1171,8 @@ PD bool cnode_step(const DevScene& S, uint32_t e, const RaySpace& C, const CRay&
     return true;
 }
 template <uint32_t ARITY>
-PD uint32_t wide_root_of(const DevScene& S, const pbrs_instance& in, uint32_t inst) {
-    return ARITY == 2u ? S.wroot[inst] : in.pad[1];
+PD uint32_t wide_root_of(const DevScene& S, const InstHead& H, uint32_t inst) {
+    return ARITY == 2u ? S.wroot[inst] : H.wide_root;
 }
 // One node step's test and pushes on pair nodes: the survivor visited first is returned (PBRS_WREF_NONE: neither passed),
 // the other one pushed; `false`: the push might not fit (the binary walk takes the ray).
@@ -1369,7 +1383,8 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             B::analytic_visit(S, in, kind, cnt);
             return;
         }
-        const uint32_t space = enter_instance(S, in, C, kind == PBRS_SHAPE_MESH, stk);
+        const InstHead H = load_inst_head(in);
+        const uint32_t space = enter_instance(S, in, H.flags, C, kind == PBRS_SHAPE_MESH, stk);
         moved = space != PBRS_SPACE_WORLD;
         in_blas = true;
         blas_base = 0;
@@ -1380,21 +1395,21 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
                 mode = PBRS_WALK_SLOW;
                 return;
             }
-            inst_info = kind | (in.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
+            inst_info = kind | (H.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
             if constexpr (ARITY == 1u) {  // the ray on the grid of this mesh; the root's record is tested like any other, against the incoming extent
                 if (!W.set(C, S.cframes[cur_inst])) mode = PBRS_WALK_SLOW;  // too far from this mesh's grid: the binary walk's ray
-                cur = in.blas_root;
+                cur = H.blas_root;
                 return;
             }
             if constexpr (ARITY != 1u)
                 if (space == PBRS_SPACE_MOVED) W.set(C);  // a new direction (make_space has just computed its reciprocals); else the world's stands
-            const uint32_t wroot = wide_root_of<ARITY>(S, in, cur_inst);
+            const uint32_t wroot = wide_root_of<ARITY>(S, H, cur_inst);
             if (wroot == PBRS_WREF_NONE) {  // the mesh is one leaf: its box is tested, against the incoming extent, with its triangles
-                hold_leaf(in.blas_root);
+                hold_leaf(H.blas_root);
                 return;
             }
             // the root against the incoming extent (blas.rs:441 at the first pop), the reference's test; then lt = mt (:468)
-            if (!slab_rs(load_node(S.nodes + in.blas_root), exact_w(), lt)) {
+            if (!slab_rs(load_node(S.nodes + H.blas_root), exact_w(), lt)) {
                 mode = B::exit_mode();
                 return;
             }
@@ -1402,8 +1417,8 @@ struct ClosestWalkW : ClosestWalk<false, FEAT> {
             cur = wroot;
         } else if (kind == PBRS_SHAPE_TRIANGLE) {
             inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
-            leaf_a = in.blas_root;
-            leaf_end = in.blas_root + 1u;
+            leaf_a = H.blas_root;
+            leaf_end = H.blas_root + 1u;
             mode = PBRS_WALK_LEAF;
         }
     }
@@ -1648,7 +1663,8 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             B::analytic_visit(S, in, cnt);
             return;
         }
-        const uint32_t space = enter_instance(S, in, C, inst_kind == PBRS_SHAPE_MESH, stk);
+        const InstHead H = load_inst_head(in);
+        const uint32_t space = enter_instance(S, in, H.flags, C, inst_kind == PBRS_SHAPE_MESH, stk);
         moved = space != PBRS_SPACE_WORLD;
         in_blas = true;
         blas_base = 0;
@@ -1660,27 +1676,27 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             if (space == PBRS_SPACE_TRANSLATED) inst_kind |= 0x100u;
             if constexpr (ARITY == 1u) {
                 if (!W.set(C, S.cframes[leaf_a])) mode = PBRS_WALK_SLOW;
-                cur = in.blas_root;
+                cur = H.blas_root;
                 return;
             }
             if constexpr (ARITY != 1u)
                 if (space == PBRS_SPACE_MOVED) W.set(C);
-            const uint32_t wroot = wide_root_of<ARITY>(S, in, leaf_a);
+            const uint32_t wroot = wide_root_of<ARITY>(S, H, leaf_a);
             if (wroot == PBRS_WREF_NONE) {
-                hold_leaf(in.blas_root);
+                hold_leaf(H.blas_root);
                 return;
             }
             // The root's own test is not needed for the answer (any hit: inner-node tests only prune), but it is one test that ends most
             // misses here — also behind an identity transform, where the scan has tested the same box: skipping it there was
             // measured slower (C4 k_shadow 238.5 -> 241.5 ms per frame; the first wide node's four tests cost more than this one)
-            if (!slab_rs(load_node(S.nodes + in.blas_root), exact_w(), t_max)) {
+            if (!slab_rs(load_node(S.nodes + H.blas_root), exact_w(), t_max)) {
                 mode = B::exit_mode();
                 return;
             }
             cur = wroot;
         } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {
-            leaf_a = in.blas_root;
-            leaf_end = in.blas_root + 1u;
+            leaf_a = H.blas_root;
+            leaf_end = H.blas_root + 1u;
             mode = PBRS_WALK_LEAF;
         }
     }
