@@ -303,7 +303,8 @@ class Workload:
                 "queue_state_bytes_per_launch": dom["queue_state_bytes_per_launch"], "scene_miss_bytes_per_launch": dom["scene_miss_bytes_per_launch"],
                 "scene_bytes_per_launch": dom["scene_bytes_per_launch"], "cache_work_rate_GBps": dom["cache_work_rate_GBps"],
                 "ms_per_launch": dom["ms_per_launch"], "launches_per_step": dom["launches"],
-                "valu_issue_frac": dom.get("valu_issue_frac"), "valu_lanes_active": dom.get("valu_lanes_active"),
+                "valu_issue_frac": dom.get("valu_issue_frac"), "valu_issue_frac_min": dom.get("valu_issue_frac_min"),
+                "valu_lanes_active": dom.get("valu_lanes_active"),
                 "l1_access_frac": dom.get("l1_access_frac"), "l1_accesses_per_launch": dom.get("l1_accesses_per_launch"),
                 "ta_busy_share": dom.get("ta_busy_share"), "td_busy_share": dom.get("td_busy_share"),
                 "note": "rank 0's kernels, the stage with the most time per frame; bound = the resource the kernel fills the largest share of: "
@@ -317,8 +318,9 @@ class Workload:
                         "offline on the same sources (source hash checked), see profiles/; "
                         "cache_work_rate prices every node / triangle visit at record size and is NOT an HBM figure; valu_issue_frac = "
                         "share of the chip's vector issue slots the kernel fills (wave-level VALU instructions per launch from the SQ "
-                        "pass in profiles/, x 4 cycles, over 1024 SIMDs x the live kernel time x 2.4 GHz): an upper bound — 32-bit-encoded f32 / "
-                        "integer instructions issue in 2.7 cycles, 64-bit encodings, f64 and conversions in about 4 (tools/microbench/issue_rates.hip)",
+                        "pass in profiles/, x the nominal 4 cycles, over 1024 SIMDs x the live kernel time x 2.4 GHz): an upper bound that can pass 1 — "
+                        "32-bit-encoded f32 / integer instructions issue in 2.7 cycles, 64-bit encodings, f64 and conversions in about 4 "
+                        "(tools/microbench/issue_rates.hip); valu_issue_frac_min = the same count at 2.7 cycles each: the true share lies between",
             },
             "traversal": trav,
             "stages_ms_per_step": times,

@@ -47,6 +47,8 @@ CLOCK_HZ = 2.4e9        # peak engine clock (same guide); the sustained clock is
 # transcendentals.  The fraction below prices every instruction at 4: an UPPER bound of the share of issue slots a kernel fills
 # (rounds 1 and 2 took it for the exact figure); with the traversal kernels' mix it is about 0.8 of that.
 CYCLES_PER_WAVE_VALU = 4
+# ... what the 32-bit-encoded f32 / integer instructions — most of a traversal step — were measured to take (tools/microbench/issue_rates.hip)
+CYCLES_PER_WAVE_VALU_MIN = 2.7
 N_CU = 256
 L1_ACCESSES_PER_CU_CYCLE = 1.0  # a CU's L1 takes one access (one lane of a load whose lanes name different lines) per cycle,
                                 # whatever the load's width: tools/microbench/gather_rates.hip, 64.6 cycles per 64-lane load
@@ -195,6 +197,9 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None):
             out[stage]["valu_insts_per_launch"] = valu[0]
             out[stage]["valu_lanes_active"] = valu[1]
             out[stage]["valu_issue_frac"] = valu[0] * CYCLES_PER_WAVE_VALU / (N_SIMD * sec * CLOCK_HZ)
+            # the same count at the cheapest measured issue cost: the true share lies between the two (the nominal figure
+            # passes 1 where most instructions are the 2.7-cycle kind)
+            out[stage]["valu_issue_frac_min"] = valu[0] * CYCLES_PER_WAVE_VALU_MIN / (N_SIMD * sec * CLOCK_HZ)
         l1 = kernel_field(traffic_doc, kernel, "l1_accesses", launches)
         if l1 is not None and sec > 0:
             # share of the L1s' access slots: a load whose 64 lanes name 64 lines is 64 accesses whatever its width, so a walk's

@@ -65,6 +65,7 @@ def test_vector_issue_share_from_the_sq_pass():
     e = rep["extend"]
     assert e["valu_insts_per_launch"] == 1.2e6 and e["valu_lanes_active"] == 40.0
     assert e["valu_issue_frac"] == 1.2e6 * 4 / (1024 * 1.0e-3 * 2.4e9)  # 2.0 ms over 2 launches
+    assert abs(e["valu_issue_frac_min"] - e["valu_issue_frac"] * 2.7 / 4) < 1e-12  # ... at the cheapest measured issue cost
     assert "valu_issue_frac" not in rep["shade"] and "valu_issue_frac" not in rep["shadow"]  # no SQ figures: not reported
 
 
