@@ -268,6 +268,11 @@ typedef struct pbrs_stats {
     /* HIP-event time per stage, summed over launches, in ms, on the context's stream */
     float ms_raygen, ms_extend, ms_shade, ms_shadow, ms_accumulate, ms_total;
     uint32_t launches_extend, launches_shadow, launches_shade, passes;
+    /* Which instantiation of the traversal kernels the render's passes launched (always filled): bit 0 analytic shapes, 1 per-candidate
+     * shading check, 2 scanned TLAS, 3 several node steps per round (deep BLAS), 4 walks over four-wide nodes, 5 full further node
+     * steps (scene beyond the last-level cache, pbrs_set_cache_bytes), 6 scene arrays staged in LDS; 0x80000000: the instrumented
+     * variant (collect_counters). */
+    uint32_t kernel_features_extend, kernel_features_shadow;
     /* Queue sizes per bounce, summed over the passes of the render (filled with the work counters): paths_at_bounce[b] = rays
      * `scene.tlas.intersect` sees at `for bounces in 0..depth` iteration b (src/pathintegrator.rs:14-16), i.e. k_extend's queue;
      * shadow_rays_at_bounce[b] = `scene.tlas.occludes` calls of that iteration's light estimate (k_shadow's queue).
@@ -286,6 +291,11 @@ const char* pbrs_last_error(const pbrs_ctx*);
 /* Run the pipeline on an existing HIP stream (e.g. torch's current stream); NULL = the context's own, which is
  * created hipStreamNonBlocking: see "Stream ordering" above. */
 int pbrs_set_stream(pbrs_ctx*, void* hip_stream);
+
+/* The size of the last-level cache the per-scene kernel choices of pbrs_upload_scene assume (0 = the default, 256 MiB: MI355X's
+ * Infinity Cache).  A scene whose traversal arrays (BVH nodes, triangle vertices, instance records) exceed it gets the traversal
+ * kernels tuned for node fetches that go to HBM.  Takes effect at the next pbrs_upload_scene; the image never depends on it. */
+int pbrs_set_cache_bytes(pbrs_ctx*, uint64_t bytes);
 
 /* Copies the flattened scene into HBM.  Stands for building `Scene` (scene/src/lib.rs:36-63). */
 int pbrs_upload_scene(pbrs_ctx*, const pbrs_scene_desc*);
@@ -340,6 +350,15 @@ typedef struct pbrs_hit_record {
  * for n caller-supplied rays (host pointers; origins/dirs are n*3 floats). Either output may be NULL. */
 int pbrs_intersect_rays(pbrs_ctx*, uint32_t n, const float* origins, const float* dirs, const float* tmax,
                         pbrs_hit_record* hits_out, uint8_t* occluded_out);
+/* Which walks the context's last pbrs_intersect_rays call went through: every query takes the walk its stage runs in the pipeline
+ * for the uploaded scene (occlusion: the four-wide any-hit walk of k_shadow where the TLAS is scanned and the BLASes are deep
+ * enough, with its hand-off of rays outside the guarded range to the binary walk; closest hit: the binary walk).  slow_*: rays the
+ * wide walk handed to the binary walk (0 when the stage runs the binary walk anyway). */
+typedef struct pbrs_intersect_info {
+    uint32_t wide_any, wide_closest;
+    uint32_t slow_any, slow_closest;
+} pbrs_intersect_info;
+int pbrs_last_intersect_info(const pbrs_ctx*, pbrs_intersect_info* out);
 /* Camera rays of one sample index for a tile (src/main.rs:197-203, geometry/src/camera.rs:65-77). */
 int pbrs_camera_rays(pbrs_ctx*, const pbrs_camera*, const pbrs_render_params*, uint32_t sample_index, float* origins_out,
                      float* dirs_out);

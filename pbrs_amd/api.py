@@ -57,7 +57,7 @@ class Stats(C.Structure):
         "triangles", "tri_shading", "spheres", "quads", "cuboids", "disks", "shadow_tlas_nodes", "shadow_blas_nodes",
         "shadow_instances", "shadow_triangles", "shadow_prims", "invalid_samples")] +
                 [(n, C.c_float) for n in ("ms_raygen", "ms_extend", "ms_shade", "ms_shadow", "ms_accumulate", "ms_total")] +
-                [(n, C.c_uint32) for n in ("launches_extend", "launches_shadow", "launches_shade", "passes")] +
+                [(n, C.c_uint32) for n in ("launches_extend", "launches_shadow", "launches_shade", "passes", "kernel_features_extend", "kernel_features_shadow")] +
                 [("paths_at_bounce", C.c_uint64 * 16), ("shadow_rays_at_bounce", C.c_uint64 * 16)])
 
     def as_dict(self):
@@ -75,9 +75,9 @@ HIT_DTYPE = np.dtype([("t", np.float32), ("inst", np.uint32), ("prim", np.uint32
 NUMERIC_FNS = {"sin": 0, "cos": 1, "tan": 2, "atan": 3, "atan2": 4, "acos": 5, "exp": 6, "ln": 7, "hypot": 8, "div": 9,
                "sqrt": 10, "asin": 11, "powi": 12, "fract": 13, "floor": 14, "box_quotient": 15}
 
-GPU_SYMBOLS = ["pbrs_create", "pbrs_destroy", "pbrs_last_error", "pbrs_set_stream", "pbrs_upload_scene", "pbrs_render_tile",
-               "pbrs_render_tile_device", "pbrs_collect_stats", "pbrs_intersect_rays", "pbrs_camera_rays", "pbrs_numeric_eval",
-               "pbrs_render_sample_radiance"]
+GPU_SYMBOLS = ["pbrs_create", "pbrs_destroy", "pbrs_last_error", "pbrs_set_stream", "pbrs_set_cache_bytes", "pbrs_upload_scene", "pbrs_render_tile",
+               "pbrs_render_tile_device", "pbrs_collect_stats", "pbrs_intersect_rays", "pbrs_last_intersect_info", "pbrs_camera_rays",
+               "pbrs_numeric_eval", "pbrs_render_sample_radiance"]
 HOST_SYMBOLS = ["pbrs_host_scene_build", "pbrs_host_scene_free", "pbrs_host_scene_desc", "pbrs_host_scene_camera",
                 "pbrs_host_scene_stack_depth", "pbrs_host_last_error",
                 "pbrs_host_load_pbrt", "pbrs_loaded_scene_spec", "pbrs_loaded_scene_free", "pbrs_host_load_error",
@@ -134,11 +134,13 @@ def gpu_lib():
         L.pbrs_last_error.restype = C.c_char_p
         L.pbrs_last_error.argtypes = [C.c_void_p]
         L.pbrs_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.pbrs_set_cache_bytes.argtypes = [C.c_void_p, C.c_uint64]
         L.pbrs_upload_scene.argtypes = [C.c_void_p, C.c_void_p]
         L.pbrs_render_tile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pbrs_render_tile_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pbrs_collect_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.pbrs_intersect_rays.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
+        L.pbrs_last_intersect_info.argtypes = [C.c_void_p, C.c_void_p]
         L.pbrs_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pbrs_numeric_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pbrs_render_sample_radiance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -257,6 +259,10 @@ class Context:
     def set_stream(self, hip_stream_ptr):
         self._check(self._L.pbrs_set_stream(self._h, C.c_void_p(hip_stream_ptr)), "pbrs_set_stream")
 
+    def set_cache_bytes(self, nbytes):
+        """The last-level cache size the per-scene kernel choices of the next upload assume (0: the default, 256 MiB)."""
+        self._check(self._L.pbrs_set_cache_bytes(self._h, int(nbytes)), "pbrs_set_cache_bytes")
+
     def upload(self, host_scene):
         self._check(self._L.pbrs_upload_scene(self._h, C.addressof(host_scene.desc)), "pbrs_upload_scene")
         self.scene = host_scene
@@ -310,6 +316,12 @@ class Context:
                                                 hits.ctypes.data if closest else None, occ.ctypes.data if anyhit else None),
                     "pbrs_intersect_rays")
         return hits, occ
+
+    def last_intersect_info(self):
+        """Which walks the last intersect() went through (include/pbrs_gpu.h, pbrs_intersect_info)."""
+        v = (C.c_uint32 * 4)()
+        self._check(self._L.pbrs_last_intersect_info(self._h, C.addressof(v)), "pbrs_last_intersect_info")
+        return {"wide_any": int(v[0]), "wide_closest": int(v[1]), "slow_any": int(v[2]), "slow_closest": int(v[3])}
 
     def camera_rays(self, sample, strata_x, strata_y, seed, tile=None):
         p = self._params(strata_x, strata_y, 1, seed, tile)

@@ -17,6 +17,9 @@
 #include "lights.h"
 #include "textures.h"
 #include "traverse.h"
+#ifdef PBRS_DEV_OVERRIDES
+#include "experimental/closest_wide.h"
+#endif
 
 struct PathState {
     // Path records by queue position i, structure-of-float4-arrays, ping-pong by bounce parity (k_shade reads set b & 1
@@ -206,103 +209,27 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #ifndef PBRS_SHD_LEAF_MIN
 #define PBRS_SHD_LEAF_MIN 8
 #endif
-// Developer probe (tools/trav_probe.py; -DPBRS_PROBE_TRAV builds only): what the traversal loops execute, summed over a launch's
-// waves.  kp[]: 0 loop rounds, 1 refills, 2 rays started, 3 boundary-step executions, 4 lanes in them, 5 / 6 / 7 lanes in a round's first /
-// second / third node step, 8 leaf-step executions, 9 lanes holding a leaf in them, 10 lanes with a walk at the start of a round,
-// 11 rounds whose first node step had a lane; then the walks' own eight counters (traverse.h).  [0]: k_extend, [1]: k_shadow.
-// ... and where a wave's cycles go (-DPBRS_PROBE_TIME, tools/trav_time.py): s_memtime at the boundaries of the loop's regions —
-// 0 refill (retire, fetch, start, scan), 1 boundary step (with its ballots), 2 node steps, 3 leaf step — summed over the waves.
-#ifdef PBRS_PROBE_TIME
-__device__ unsigned long long g_trav_time[2][8];
-#define PBRS_TT_DECL                                       \
-    unsigned long long tt[4] = {0ull, 0ull, 0ull, 0ull};   \
-    unsigned long long tprev = __builtin_amdgcn_s_memtime()
-#define PBRS_TT(i)                                                      \
-    do {                                                                \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
-        tt[i] += now_ - tprev;                                          \
-        tprev = now_;                                                   \
-    } while (0)
-#define PBRS_TT_FLUSH(which)                                                             \
-    do {                                                                                 \
-        if ((threadIdx.x & 63u) == 0u)                                                   \
-            for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_trav_time[which][k_], tt[k_]);   \
-    } while (0)
-#else
-#define PBRS_TT_DECL \
-    do {             \
-    } while (0)
-#define PBRS_TT(i) \
-    do {           \
-    } while (0)
-#define PBRS_TT_FLUSH(which) \
-    do {                     \
-    } while (0)
-#endif
-#ifdef PBRS_PROBE_TRAV
-__device__ unsigned long long g_trav_probe[2][24];
-#define PBRS_KP_DECL(walk)      \
-    uint32_t kp[16];            \
-    for (int k_ = 0; k_ < 16; ++k_) kp[k_] = 0; \
-    for (int k_ = 0; k_ < PBRS_TP_N; ++k_) walk.pr[k_] = 0
-#define PBRS_KP_LANE(i, cond)  \
-    do {                       \
-        if (cond) kp[i]++;     \
-    } while (0)
-#define PBRS_KP_WAVE(i) PBRS_KP_LANE(i, (threadIdx.x & 63u) == 0u)  /* wave-uniform control flow only */
-PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
-    for (int k = 0; k < 24; ++k) {
-        uint32_t v = k < 16 ? kp[k] : pr[k - 16];
-        unsigned long long t = v;
-        for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o, 64);
-        if ((threadIdx.x & 63u) == 0u && t) atomicAdd(&g_trav_probe[which][k], t);
-    }
-}
-#define PBRS_KP_FLUSH(which, walk) trav_probe_flush(which, kp, walk.pr)
-#else
-#define PBRS_KP_DECL(walk) \
-    do {                   \
-    } while (0)
-#define PBRS_KP_LANE(i, cond) \
-    do {                      \
-    } while (0)
-#define PBRS_KP_WAVE(i) \
-    do {                \
-    } while (0)
-#define PBRS_KP_FLUSH(which, walk) \
-    do {                           \
-    } while (0)
-#endif
 // Scenes with long walks (a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: PBRS_FEAT_LONG_WALKS) take PBRS_NODE_STEPS_LONG
 // node steps per loop round: most rounds of a deep walk are node steps, and the checks around them (who waits at a
 // boundary, who holds a leaf, who is done) then run a third as often.  C4 (23 levels), ms per frame extend / shadow at
 // 1 / 2 / 3 / 4 / 6 steps: 562 / 530 / 523 / 523 / 537 and 321 / 301 / 295 / 295 / 301; short walks lose (two steps: C2 -2 %,
 // C3 -1 %: the later steps run at few lanes) and keep one.
-#ifdef PBRS_FULL_FURTHER_STEPS  /* A/B: every node step of a round is the full one */
-#define PBRS_FURTHER_NODE_STEP(walk, S, stk, cnt) walk.node_step(S, stk, cnt)
-#define PBRS_FIRST_NODE_STEP(walk, S, stk, cnt) walk.node_step(S, stk, cnt)
-#else
-#define PBRS_FURTHER_NODE_STEP(walk, S, stk, cnt) walk.node_step_fast(S, stk, cnt)
-#ifdef PBRS_FLOOR_FIRST_STEP  /* A/B: a floor step, then lean steps only — measured even on C4 (444.3 against 444.0 ms), 2 % behind on C2 */
-#define PBRS_FIRST_NODE_STEP(walk, S, stk, cnt) walk.first_node_step(S, stk, cnt)
-#else
-#define PBRS_FIRST_NODE_STEP(walk, S, stk, cnt) walk.node_step(S, stk, cnt)
-#endif
-#endif
-#define PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS)                            \
+// A round's further node steps are LEAN ones (traverse.h, node_step_fast: pop, test, push; a lane at the floor of its tree waits for
+// the round's first step) where the scene's nodes live in the caches — C4 +2 % — and FULL ones (PBRS_FEAT_FULL_STEPS) where node
+// fetches go to HBM: there a round is long and the lanes a lean step leaves waiting are what the wave's time is made of (c4xl: 742
+// against 657 Msamples/s, profiles/r03m_ab_c4xl_lean_steps.log).  pbrs_upload_scene chooses per scene by the size of what the walks
+// read against the last-level cache (pbrs_set_cache_bytes).
+#define PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS, FULL)                      \
     do {                                                                           \
-        if ((NSTEPS) == 0u && __ballot(walk.mode == PBRS_WALK_NODE)) { /* as long as most of the wave wants one: a loop of its own, whose registers the allocator serves first */ \
-            _Pragma("nounroll") do {                                               \
-                PBRS_KP_LANE(6, walk.mode == PBRS_WALK_NODE);                      \
-                if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);      \
-            } while ((uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_NODE)) >= PBRS_NODE_LOOP_MIN); \
-        }                                                                          \
         _Pragma("unroll") for (uint32_t k_ = 1; k_ < (NSTEPS); ++k_) {             \
             PBRS_KP_LANE(5 + (k_ < 2u ? k_ : 2u), walk.mode == PBRS_WALK_NODE);    \
-            if (walk.mode == PBRS_WALK_NODE) PBRS_FURTHER_NODE_STEP(walk, S, stk, cnt); \
+            if (walk.mode == PBRS_WALK_NODE) {                                     \
+                if constexpr (FULL) walk.node_step(S, stk, cnt);                   \
+                else walk.node_step_fast(S, stk, cnt);                             \
+            }                                                                      \
         }                                                                          \
     } while (0)
-#define PBRS_STEP_WALK(walk, S, stk, cnt, XFER_MIN, LEAF_MIN, NSTEPS)                                                  \
+#define PBRS_STEP_WALK(walk, S, stk, cnt, XFER_MIN, LEAF_MIN, NSTEPS, FULL)                                                \
     do {                                                                                                       \
         PBRS_KP_WAVE(0);                                                                                       \
         PBRS_KP_LANE(10, walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER); \
@@ -319,8 +246,8 @@ PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
         PBRS_PROBE_UTIL_COUNT(walk, cnt);                                                                      \
         PBRS_KP_LANE(5, walk.mode == PBRS_WALK_NODE);                                                          \
         if (__ballot(walk.mode == PBRS_WALK_NODE)) PBRS_KP_WAVE(11);                                           \
-        if ((NSTEPS) != 0u && walk.mode == PBRS_WALK_NODE) PBRS_FIRST_NODE_STEP(walk, S, stk, cnt);            \
-        PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS);                                                              \
+        if (walk.mode == PBRS_WALK_NODE) walk.node_step(S, stk, cnt);                                          \
+        PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS, FULL);                                                            \
         PBRS_TT(2);                                                                                            \
         const uint32_t nl = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));                         \
         if (nl && (nl >= LEAF_MIN || __ballot(walk.mode == PBRS_WALK_NODE) == 0)) {                            \
@@ -331,62 +258,6 @@ PD void trav_probe_flush(int which, const uint32_t* kp, const uint32_t* pr) {
         }                                                                                                      \
         PBRS_TT(3);                                                                                            \
     } while (0)
-// developer probe (tools/util_probe.py, instrumented variant only): wave-level executions of the node and leaf steps,
-// stashed in the cuboid / disk counters of a scene that has neither
-#ifdef PBRS_PROBE_UTIL
-#define PBRS_PROBE_ONE(cond, field)                                                                            \
-    do {                                                                                                       \
-        const uint64_t pm = __ballot(cond);                                                                    \
-        if (pm && (threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)pm) - 1)) cnt.c.field++;       \
-    } while (0)
-#ifdef PBRS_PROBE_UTIL2  /* lanes per mode at the start of a round, summed by the wave's first lane */
-#define PBRS_PROBE_UTIL_COUNT(walk, cnt)                                                          \
-    do {                                                                                          \
-        if (STATS && (threadIdx.x & 63u) == 0) {                                                  \
-            cnt.c.quads += 1;                                                                     \
-        }                                                                                         \
-        if (STATS) {                                                                              \
-            const uint32_t pn_ = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_NODE));      \
-            const uint32_t pl_ = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_LEAF));      \
-            const uint32_t px_ = (uint32_t)__popcll(__ballot(walk.mode == PBRS_WALK_XFER));      \
-            if ((threadIdx.x & 63u) == 0) cnt.c.cuboids += pn_, cnt.c.disks += pl_, cnt.c.tri_shading += px_; \
-        }                                                                                         \
-    } while (0)
-#else
-#define PBRS_PROBE_UTIL_COUNT(walk, cnt)                                                          \
-    do {                                                                                          \
-        if (STATS) {                                                                              \
-            PBRS_PROBE_ONE(walk.mode == PBRS_WALK_NODE, cuboids);                                 \
-            PBRS_PROBE_ONE(true, quads);                                                          \
-        }                                                                                         \
-    } while (0)
-#endif
-#define PBRS_PROBE_XFER_COUNT(cnt)                               \
-    do {                                                         \
-        if (STATS) PBRS_PROBE_ONE(true, spheres); /* wave-level boundary-step executions */ \
-    } while (0)
-#ifdef PBRS_PROBE_UTIL2
-#define PBRS_PROBE_LEAF_COUNT(cnt) \
-    do {                           \
-    } while (0)
-#else
-#define PBRS_PROBE_LEAF_COUNT(cnt)                               \
-    do {                                                         \
-        if (STATS) PBRS_PROBE_ONE(true, disks); /* wave-level leaf-step executions */ \
-    } while (0)
-#endif
-#else
-#define PBRS_PROBE_UTIL_COUNT(walk, cnt) \
-    do {                                 \
-    } while (0)
-#define PBRS_PROBE_LEAF_COUNT(cnt) \
-    do {                           \
-    } while (0)
-#define PBRS_PROBE_XFER_COUNT(cnt) \
-    do {                           \
-    } while (0)
-#endif
-
 // Work fetch of the persistent traversal kernels.  A wave owns a private range [cur, end) of queue items and hands
 // them to its idle lanes without touching memory; only when the range is empty does its first idle lane take a new
 // chunk with one atomicAdd.  A single device-wide head word serialises at ~10 ns per atomic, which capped the kernels
@@ -467,57 +338,70 @@ PD void wave_append_slow(bool slow, uint32_t item, uint32_t* list, uint32_t* cou
 #ifndef PBRS_WIDE_NODE_STEPS  // node steps per loop round of the wide walks in scenes with long walks
 #define PBRS_WIDE_NODE_STEPS 2u
 #endif
-#ifndef PBRS_PAIR_EXTEND_WAVES  // ... and for the kernels that walk pair nodes
-#define PBRS_PAIR_EXTEND_WAVES 6
-#endif
-#ifndef PBRS_PAIR_SHADOW_WAVES
-#define PBRS_PAIR_SHADOW_WAVES 6
-#endif
-#ifndef PBRS_PAIR_NODE_STEPS
-#define PBRS_PAIR_NODE_STEPS 2u
-#endif
-#ifndef PBRS_CNODE_EXTEND_WAVES  // ... and for the kernels that walk compressed records
-#define PBRS_CNODE_EXTEND_WAVES 6
-#endif
-#ifndef PBRS_CNODE_SHADOW_WAVES
-#define PBRS_CNODE_SHADOW_WAVES 6
-#endif
-#ifndef PBRS_CNODE_NODE_STEPS
-#define PBRS_CNODE_NODE_STEPS 3u  // 0: node steps in a loop of their own while PBRS_NODE_LOOP_MIN lanes want one
-#endif
-#ifndef PBRS_NODE_LOOP_MIN
-#define PBRS_NODE_LOOP_MIN 36u
-#endif
-template <uint32_t ARITY, bool STATS, uint32_t FEAT>  // ARITY 0: the binary walks
+template <uint32_t ARITY, bool STATS, uint32_t FEAT>  // ARITY 0: the binary walks; 4: the walks over four-wide nodes (device/wide.h)
 struct ClosestSel {
-    typedef ClosestWalkW<FEAT, ARITY> type;
+#ifdef PBRS_DEV_OVERRIDES
+    typedef ClosestWalkW<FEAT> type;  // device/experimental/closest_wide.h
+#endif
 };
 template <bool STATS, uint32_t FEAT>
 struct ClosestSel<0u, STATS, FEAT> {
-    typedef ClosestWalk<STATS, (FEAT & PBRS_FEAT_ALL), !STATS && (FEAT & PBRS_FEAT_GRID) != 0u> type;
+    typedef ClosestWalk<STATS, (FEAT & PBRS_FEAT_ALL)> type;
 };
 template <uint32_t ARITY, bool STATS, uint32_t FEAT>
 struct AnySel {
-    typedef AnyWalkW<FEAT, ARITY> type;
+    typedef AnyWalkW<FEAT> type;
 };
 template <bool STATS, uint32_t FEAT>
 struct AnySel<0u, STATS, FEAT> {
-    typedef AnyWalk<STATS, (FEAT & PBRS_FEAT_ALL), !STATS && (FEAT & PBRS_FEAT_GRID) != 0u> type;
+    typedef AnyWalk<STATS, (FEAT & PBRS_FEAT_ALL)> type;
 };
-#define PBRS_WALK_ARITY(STATS, FEAT) ((STATS) ? 0u : ((FEAT) & PBRS_FEAT_CNODE) ? 1u : ((FEAT) & PBRS_FEAT_PAIR) ? 2u : ((FEAT) & PBRS_FEAT_WIDE) ? 4u : 0u)
+#define PBRS_WALK_ARITY(STATS, FEAT) ((STATS) ? 0u : ((FEAT) & PBRS_FEAT_WIDE) ? 4u : 0u)
 #ifndef PBRS_NODE_STEPS_SHORT  // node steps per round in scenes with short walks: one (two, the second a lean one: C2 -2.3 %, C3 -3.2 %)
 #define PBRS_NODE_STEPS_SHORT 1u
 #endif
 #define PBRS_WALK_NSTEPS(FEAT, ARITY) \
-    (!((FEAT) & PBRS_FEAT_LONG_WALKS) ? ((ARITY) == 0u ? PBRS_NODE_STEPS_SHORT : 1u) : (ARITY) == 1u ? PBRS_CNODE_NODE_STEPS : (ARITY) == 2u ? PBRS_PAIR_NODE_STEPS : (ARITY) == 4u ? PBRS_WIDE_NODE_STEPS : PBRS_NODE_STEPS_LONG)
+    (!((FEAT) & PBRS_FEAT_LONG_WALKS) ? ((ARITY) == 0u ? PBRS_NODE_STEPS_SHORT : 1u) : (ARITY) == 4u ? PBRS_WIDE_NODE_STEPS : PBRS_NODE_STEPS_LONG)
+// PBRS_FEAT_LDS_SCENE: a random 16-byte read costs the CU's texture path 2 cycles per lane (a 32-byte node 129 cycles per wave, a
+// 48-byte triangle ~190) and the LDS 0.37 (a node 46-58, a triangle 36-50: tools/microbench/gather_lds_coop.hip,
+// profiles/r04_microbench_gather_lds_coop.log), at a third of the latency.  Where the arrays a walk reads fit next to the block's stack
+// rows (pbrs_upload_scene: C2 / C3, 8 KB) every block copies them in once and the walk's scene view points into the copy: node,
+// triangle, instance and shape fetches become ds_read_b128; what stays on the texture path is a ray's own record (fetched at its
+// start, read again when it leaves an instance) and its result.
+PD DevScene stage_scene(const DevScene& G, uint32_t* lds_base) {
+    DevScene S = G;
+    uint4* dst = reinterpret_cast<uint4*>(__builtin_assume_aligned(lds_base + G.lds_off_words, 16));
+    const uint32_t n_nodes = G.lds_nodes * (uint32_t)(sizeof(pbrs_node) / 16), n_tv = G.lds_tris * (uint32_t)(sizeof(pbrs_tri_verts) / 16),
+                   n_inst = G.lds_inst * (uint32_t)(sizeof(pbrs_instance) / 16), n_shapes = G.lds_shapes * (uint32_t)(sizeof(pbrs_shape) / 16);
+    const uint4* src = reinterpret_cast<const uint4*>(G.nodes);
+    for (uint32_t i = threadIdx.x; i < n_nodes; i += PBRS_TRAVERSAL_BLOCK) dst[i] = src[i];
+    S.nodes = reinterpret_cast<const pbrs_node*>(dst);
+    dst += n_nodes;
+    src = reinterpret_cast<const uint4*>(G.tv);
+    for (uint32_t i = threadIdx.x; i < n_tv; i += PBRS_TRAVERSAL_BLOCK) dst[i] = src[i];
+    S.tv = reinterpret_cast<const pbrs_tri_verts*>(dst);
+    dst += n_tv;
+    src = reinterpret_cast<const uint4*>(G.inst);
+    for (uint32_t i = threadIdx.x; i < n_inst; i += PBRS_TRAVERSAL_BLOCK) dst[i] = src[i];
+    S.inst = reinterpret_cast<const pbrs_instance*>(dst);
+    dst += n_inst;
+    src = reinterpret_cast<const uint4*>(G.shapes);
+    for (uint32_t i = threadIdx.x; i < n_shapes; i += PBRS_TRAVERSAL_BLOCK) dst[i] = src[i];
+    S.shapes = reinterpret_cast<const pbrs_shape*>(dst);
+    __syncthreads();
+    return S;
+}
+static_assert(sizeof(pbrs_node) % 16 == 0 && sizeof(pbrs_tri_verts) % 16 == 0 && sizeof(pbrs_instance) % 16 == 0 && sizeof(pbrs_shape) % 16 == 0, "stage_scene copies 16-byte pieces");
+
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
 // handed a new ray at the next refill, the walks of the other lanes continue where they were.
 // `indirect` (binary-walk kernels working off a slow list): the queue positions to trace, `count` of them.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PBRS_CNODE_EXTEND_WAVES : (FEAT & PBRS_FEAT_PAIR) ? PBRS_PAIR_EXTEND_WAVES : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_EXTEND_WAVES : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES)
-    k_extend(DevScene S, PathState st, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect,
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_EXTEND_WAVES : (FEAT & PBRS_FEAT_SHADING_CHECK) ? PBRS_TRAV_WAVES : PBRS_LEAN_EXTEND_WAVES)
+    k_extend(DevScene G, PathState st, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect,
              uint32_t* slow_list, uint32_t* slow_count, uint32_t split) {
-    extern __shared__ uint32_t lds_stack[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const DevScene S = (!STATS && (FEAT & PBRS_FEAT_LDS_SCENE)) ? stage_scene(G, lds_stack) : G;
     constexpr uint32_t ARITY = PBRS_WALK_ARITY(STATS, FEAT);
     constexpr bool WIDE = ARITY != 0u;
     const uint32_t n = count ? *count : n_direct;
@@ -527,8 +411,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
-    typename ClosestSel<ARITY, STATS, (ARITY ? (FEAT & PBRS_FEAT_ALL) : (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_GRID)))>::type walk;
-    constexpr bool GRID = !STATS && ARITY == 0u && (FEAT & PBRS_FEAT_GRID) != 0u;
+    typename ClosestSel<ARITY, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
     PBRS_TT_DECL;
@@ -582,7 +465,6 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
                 }
                 if constexpr (WIDE) walk.scan_wave(S, stk);
                 else walk.scan_wave(S, cnt);
-                if constexpr (GRID) walk.forget_reciprocals();  // the scan was their last reader (exact_space recomputes them)
                 live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
             if (live == 0) {
@@ -594,28 +476,13 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
             }
         }
         PBRS_TT(0);
-        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY));
-        if constexpr (WIDE || GRID) walk.forget_reciprocals();
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_EXT_XFER_MIN, PBRS_EXT_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY), ((FEAT & PBRS_FEAT_FULL_STEPS) != 0u));
+        if constexpr (WIDE) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, nhit);
     if (!STATS) PBRS_KP_FLUSH(0, walk);
     if (!STATS) PBRS_TT_FLUSH(0);
 }
-
-// Developer probe (tools/shade_probe.py; -DPBRS_PROBE_SHADE builds only): wall cycles of k_shade's regions, summed per wave.
-#ifdef PBRS_PROBE_SHADE
-__device__ unsigned long long g_shade_probe[16];
-#define PBRS_SHADE_MARK(k)                                          \
-    do {                                                            \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        probe_acc[k] += now_ - probe_t;                             \
-        probe_t = now_;                                             \
-    } while (0)
-#else
-#define PBRS_SHADE_MARK(k) \
-    do {                   \
-    } while (0)
-#endif
 
 PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:224-232, BETA = 2, nf = ng = 1
     float f = 1.0f * f_pdf;
@@ -1225,10 +1092,11 @@ __global__ void __launch_bounds__(256) k_class_scatter(PathState st, const uint3
 // ---- shadow ----------------------------------------------------------------------------------------------------
 // One work item per shadow ray (persistent, same refill scheme as k_extend); writes one occlusion byte.
 template <bool STATS, uint32_t FEAT>
-__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PBRS_CNODE_SHADOW_WAVES : (FEAT & PBRS_FEAT_PAIR) ? PBRS_PAIR_SHADOW_WAVES : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_SHADOW_WAVES : PBRS_SHADOW_WAVES)
-    k_shadow(DevScene S, PathState st, const uint32_t* count, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect, uint32_t* slow_list,
+__global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBRS_WIDE_SHADOW_WAVES : PBRS_SHADOW_WAVES)
+    k_shadow(DevScene G, PathState st, const uint32_t* count, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect, uint32_t* slow_list,
              uint32_t* slow_count) {
-    extern __shared__ uint32_t lds_stack[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const DevScene S = (!STATS && (FEAT & PBRS_FEAT_LDS_SCENE)) ? stage_scene(G, lds_stack) : G;
     constexpr uint32_t ARITY = PBRS_WALK_ARITY(STATS, FEAT);
     constexpr bool WIDE = ARITY != 0u;
     const uint32_t n = indirect ? count[0] : count[1];  // a slow list's length, or the high half of the packed (nee paths, shadow rays) counter
@@ -1236,8 +1104,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
-    typename AnySel<ARITY, STATS, (ARITY ? (FEAT & PBRS_FEAT_ALL) : (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_GRID)))>::type walk;
-    constexpr bool GRID = !STATS && ARITY == 0u && (FEAT & PBRS_FEAT_GRID) != 0u;
+    typename AnySel<ARITY, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
     PBRS_TT_DECL;
@@ -1282,7 +1149,6 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
                 }
                 if constexpr (WIDE) walk.scan_wave(S, stk);
                 else walk.scan_wave(S, cnt);
-                if constexpr (GRID) walk.forget_reciprocals();  // the scan was their last reader (exact_space recomputes them)
                 live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
             }
             if (live == 0) {
@@ -1294,8 +1160,8 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_CNODE) ? PB
             }
         }
         PBRS_TT(0);
-        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY));
-        if constexpr (WIDE || GRID) walk.forget_reciprocals();
+        PBRS_STEP_WALK(walk, S, stk, cnt, PBRS_SHD_XFER_MIN, PBRS_SHD_LEAF_MIN, PBRS_WALK_NSTEPS(FEAT, ARITY), ((FEAT & PBRS_FEAT_FULL_STEPS) != 0u));
+        if constexpr (WIDE) walk.forget_reciprocals();
     }
     flush_counters<STATS>(cnt, gc, true, nrays, 0u);
     if (!STATS) PBRS_KP_FLUSH(1, walk);
@@ -1370,11 +1236,13 @@ __global__ void k_sum_bounce_counts(const uint32_t* act, const unsigned long lon
 }
 
 // ---- parity-harness kernels --------------------------------------------------------------------------------------------
-// WIDE: through the walks over four-wide nodes (the kernels the pipeline runs for scenes with a scanned TLAS), else the binary walks.
-template <bool WIDE>
+// The walks the pipeline runs for the scene, chosen per stage exactly as run_pass chooses them: WIDE_ANY = occlusion queries go through
+// the four-wide any-hit walk of k_shadow (AnyWalkW, with its hand-off of refused rays to the binary walk); WIDE_CLOSEST = the
+// four-wide closest-hit walk (developer builds only).  info[0] / info[1]: rays the wide any-hit / closest-hit walk refused.
+template <bool WIDE_CLOSEST, bool WIDE_ANY>
 __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, const float4* origins, const float4* dirs, const float* tmax,
-                                                       pbrs_hit_record* hits, uint8_t* occluded, uint32_t stack_rows) {
-    extern __shared__ uint32_t lds_stack[];
+                                                       pbrs_hit_record* hits, uint8_t* occluded, uint32_t* info) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     LaneStack stk{lds_stack + threadIdx.x, origins, dirs, 0u};
     Cnt<false> cnt;
     // grid <= PBRS_PERSISTENT_BLOCKS; whole blocks stay in the loop together (the walks share work across a wave)
@@ -1391,8 +1259,12 @@ __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, 
         }
         if (hits) {
             Hit h;
-            if (WIDE) tlas_closest_wide(S, active, o, d, t_max, stk, h);
-            else tlas_closest<false>(S, active, o, d, t_max, stk, h, cnt);
+            bool slow = false;
+#ifdef PBRS_DEV_OVERRIDES
+            if constexpr (WIDE_CLOSEST) tlas_closest_wide(S, active, o, d, t_max, stk, h, slow);
+            else
+#endif
+                tlas_closest<false>(S, active, o, d, t_max, stk, h, cnt);
             if (active) {
                 pbrs_hit_record r;
                 r.t = h.t;
@@ -1402,11 +1274,16 @@ __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, 
                 r.b1 = h.b1;
                 r.b2 = h.b2;
                 hits[i] = r;
+                if (slow) atomicAdd(info + 1, 1u);
             }
         }
         if (occluded) {
-            const bool occ = WIDE ? tlas_any_wide(S, active, o, d, t_max, stk) : tlas_any<false>(S, active, o, d, t_max, stk, cnt);
-            if (active) occluded[i] = occ ? 1 : 0;
+            bool slow = false;
+            const bool occ = WIDE_ANY ? tlas_any_wide(S, active, o, d, t_max, stk, slow) : tlas_any<false>(S, active, o, d, t_max, stk, cnt);
+            if (active) {
+                occluded[i] = occ ? 1 : 0;
+                if (slow) atomicAdd(info, 1u);
+            }
         }
     }
 }

@@ -13,8 +13,6 @@
 #include "dmath.h"
 
 struct pbrs_wnode;  // device/wide.h
-struct pbrs_cnode;
-struct pbrs_cframe;
 struct DevScene {
     // Every BVH node of the scene in one array with absolute links: the TLAS at 0 (root = node 0), its leaves again at
     // flat_off when the TLAS is small (below), then the BLASes; a mesh instance's blas_root is an index into it.
@@ -57,13 +55,10 @@ struct DevScene {
     // and the entries a lane's stack may hold in the kernels that walk them (beyond that a ray goes to the binary-walk kernels)
     const pbrs_wnode* wnodes;
     uint32_t wide_cap;
-    // Kernels that walk pair nodes (PBRS_FEAT_PAIR) are launched with wnodes = the pair nodes, wide_cap = their stack rows, and
-    // the pair node of every mesh instance's root here (PBRS_WREF_NONE where the mesh is a single leaf)
-    const uint32_t* wroot;
-    // Compressed records of the BLAS nodes (device/wide.h): cnodes[i] for nodes[i]; cframes[instance]: the grid of its mesh.  The
-    // kernels that walk them (PBRS_FEAT_CNODE) take wide_cap = their stack rows.
-    const pbrs_cnode* cnodes;
-    const pbrs_cframe* cframes;
+    // Scenes of a few KB (a Cornell box: 8 KB): what the walks read — every node, triangle-vertex record, instance record and analytic
+    // shape — is copied into each block's LDS behind its stack rows at kernel start (PBRS_FEAT_LDS_SCENE kernels; kernels.h,
+    // stage_scene): element counts, and the word offset of the copy in the block's dynamic LDS (a multiple of 4).  0 nodes: not staged.
+    uint32_t lds_off_words, lds_nodes, lds_tris, lds_inst, lds_shapes;
 };
 
 // Scene features the traversal kernels are specialised on (pbrs_upload_scene derives them from the arrays it checks).
@@ -78,9 +73,8 @@ struct DevScene {
 #define PBRS_FEAT_ALL 7u
 #define PBRS_FEAT_LONG_WALKS 8u     // kernels only (not a property of the walks): several node steps per loop round (kernels.h)
 #define PBRS_FEAT_WIDE 16u          // kernels only: the walks over four-wide nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
-#define PBRS_FEAT_PAIR 32u          // kernels only: the same walks over pair nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
-#define PBRS_FEAT_GRID 128u         // kernels only: the BINARY walks with a mesh's box tests made on the compressed records (traverse.h, GRID); scanned TLAS only
-#define PBRS_FEAT_CNODE 64u         // kernels only: the same walks over the binary tree's compressed records (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
+#define PBRS_FEAT_LDS_SCENE 64u     // kernels only: the arrays the walks read are copied into the block's LDS at kernel start (scenes of a few KB; kernels.h)
+#define PBRS_FEAT_FULL_STEPS 32u    // kernels only (with PBRS_FEAT_LONG_WALKS): a round's further node steps are full steps (kernels.h): scenes beyond the last-level cache
 #define PBRS_FLAT_TLAS_MIN 2u
 // Largest TLAS the wave scans instead of walking (tools/tlas_probe.py, C5's scene family at 960x540, ms per 64 spp, walk vs
 // scan): closest hit 4.84 / 4.74 at 20 instances, 5.10 / 5.28 at 24, 5.66 / 6.15 at 30 — the scan only filters there and every

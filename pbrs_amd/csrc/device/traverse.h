@@ -25,19 +25,7 @@
 #pragma once
 #include "shapes.h"
 
-// Developer probe (tools/trav_probe.py; -DPBRS_PROBE_TRAV builds only): per-lane event counts of a walk — 0 node steps, 1 box
-// tests (a wide node's four count once), 2 of them failed, 3 BLAS leaves that came up, 4 of them with their own box passing,
-// 5 triangle tests run as a helper, 6 / 7 boundary steps in / out.
-#ifdef PBRS_PROBE_TRAV
-#define PBRS_TP_N 8
-#define PBRS_TP_FIELDS uint32_t pr[PBRS_TP_N];
-#define PBRS_TP(i) (this->pr[i]++)
-#else
-#define PBRS_TP_FIELDS
-#define PBRS_TP(i) \
-    do {           \
-    } while (0)
-#endif
+#include "probes.h"
 
 struct RaySpace {
     f3 o, d;
@@ -129,6 +117,14 @@ PD bool slab_rs_tlow(const pbrs_node& n, const RaySpace& R, float& t_low) {
 struct InstHead {
     uint32_t flags, blas_root, mesh_flags, wide_root;
 };
+// load_inst_head reads bytes 112 .. 127 of the public record as one vector, the walks address nodes and wide nodes by byte offsets of
+// these sizes: a field added or reordered in include/pbrs_gpu.h must not compile into out-of-bounds reads
+static_assert(offsetof(pbrs_instance, flags) == 108 && offsetof(pbrs_instance, blas_root) == 112 && offsetof(pbrs_instance, mesh_flags) == 116 &&
+                  offsetof(pbrs_instance, pad) == 120 && sizeof(pbrs_instance) == 128 && alignof(pbrs_instance) <= 16,
+              "pbrs_instance layout (load_inst_head, wide root in pad[1], shading class in pad[0])");
+static_assert(sizeof(pbrs_node) == 32 && offsetof(pbrs_node, a) == 12 && offsetof(pbrs_node, max) == 16 && offsetof(pbrs_node, b) == 28, "pbrs_node layout (load_node)");
+static_assert(sizeof(pbrs_wnode) == 128 && offsetof(pbrs_wnode, hi) == 48 && offsetof(pbrs_wnode, child) == 96, "pbrs_wnode layout (wide_test)");
+static_assert(sizeof(pbrs_tri_verts) == 48, "pbrs_tri_verts layout (load_tri)");
 PD InstHead load_inst_head(const pbrs_instance& in) {
     uint32_t f = in.flags;
     uint4 r = *reinterpret_cast<const uint4*>(&in.blas_root);  // blas_root, mesh_flags, pad[0], pad[1] (the wide root): bytes 112 .. 127
@@ -375,21 +371,7 @@ PD uint32_t flat_scan_tlow(const DevScene& S, bool fresh, const RaySpace& R, flo
     return mine;
 }
 
-// GRID walks: the binary walks below with the box tests of a mesh's nodes made on the nodes' compressed records (wide.h: one
-// 16-byte load and a filter instead of two loads and the exact test) for rays on the division-free test.  A leaf whose record
-// passes is held unverified until the shared leaf step gives it the reference's own test; the box of a scanned TLAS leaf is
-// tested, exactly, at the boundary step that would enter it; the reciprocals are recomputed for those few exact tests
-// (exact_space) instead of living in six registers.  Only for scenes whose TLAS is scanned (DevScene::n_flat != 0).
-template <bool GRID>
-struct GridSel {
-    struct type {};
-};
-template <>
-struct GridSel<true> {
-    typedef CRay type;
-};
-#define PBRS_BOX_PENDING 0x80000000u  // ClosestWalk::cur_inst of a GRID walk at a boundary: bits 0-30 name a scanned TLAS leaf whose box is still to be tested
-template <bool STATS, uint32_t FEAT, bool GRID = false>
+template <bool STATS, uint32_t FEAT>
 struct ClosestWalk {
     RaySpace C;  // the space the lane is walking in (the world ray in the TLAS, the instance's ray below a TLAS leaf): one
                  // box-test call serves lanes in either tree.  The world ray is read again on the way out (reload_world).
@@ -403,9 +385,7 @@ struct ClosestWalk {
     uint32_t cand;        // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, moved;  // moved: C is not the world ray (inst_info bit 30: only its origin differs)
     uint32_t mode;
-    typename GridSel<GRID>::type G;  // GRID walks: the ray on the grid of the mesh it is in
     PBRS_TP_FIELDS
-    PD void forget_reciprocals() { C.nr = gray(0.0f); }  // GRID walks: not state (exact_space recomputes them)
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         C = make_space(o, d, S.fast_slab != 0);
@@ -458,42 +438,6 @@ struct ClosestWalk {
             mode = exit_mode();
             return;
         }
-        if constexpr (GRID) {
-            if (sp == 0) {  // the next scanned TLAS leaf: its box gets the reference's test of this moment at the boundary step
-                if (cand == 0u) {
-                    mode = PBRS_WALK_DONE;
-                    return;
-                }
-                cur_inst = PBRS_BOX_PENDING | (uint32_t)__builtin_ctz(cand);
-                cand &= cand - 1u;
-                mode = PBRS_WALK_XFER;
-                return;
-            }
-            if (in_blas && C.fast) {  // a mesh's node through its compressed record
-                const uint32_t ni = stk.get(--sp);
-                PBRS_TP(1);
-                const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[ni];
-                if (!cnode_filter(pbrs_cnode{raw.x, raw.y, raw.z, raw.w}, G, lt)) {
-                    PBRS_TP(2);
-                    if (PBRS_EARLY_OUT && sp == blas_base) mode = exit_mode();
-                    return;
-                }
-                if (!(raw.w & PBRS_CNODE_LEAF)) {
-                    // blas.rs:456-466: the left child first iff ray.dir[axis] > 0 — the sign A = step * (1 / dir) carries
-                    const bool left_first = (__float_as_uint(comp(G.A, (int)((raw.w >> 29) & 3u))) >> 31) == 0u;
-                    const uint32_t left = ni + 1u, right = raw.w & PBRS_CNODE_CHILD_MASK;
-                    stk.put(sp++, left_first ? right : left);
-                    stk.put(sp++, left_first ? left : right);
-                    lt = mt;  // blas.rs:468
-                } else {
-                    PBRS_TP(3);
-                    leaf_a = ni;  // held unverified: leaf_wave gives it the reference's own test, with the extent of that moment
-                    leaf_end = 0xffffffffu;
-                    mode = PBRS_WALK_LEAF;
-                }
-                return;
-            }
-        }
         // One box test serves lanes at a BLAS / TLAS node and lanes whose turn it is to test a scanned leaf of a small TLAS
         // — the test the reference makes at this moment (scan_wave only filters).
         uint32_t ni;
@@ -540,43 +484,13 @@ struct ClosestWalk {
         }
     }
 
-    // What a round does before its node steps for the lanes whose stack is down to the floor of their tree: the instance is used
-    // up (the boundary step, or the end of the walk), or — at the TLAS level of a scanned TLAS — the next scanned leaf goes onto the
-    // stack, where the node step finds it like any other node (its box gets the reference's test of that moment), or the walk is
-    // over.  No load, no box test: a dozen instructions once per round instead of exec-mask bookkeeping in every node step.
-    PD void floor_step(const DevScene& S, LaneStack stk) {
-        if (in_blas) {
-            if (sp == blas_base) mode = exit_mode();
-            return;
-        }
-        if (sp != 0) return;
-        if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || cand == 0u) {
-            mode = PBRS_WALK_DONE;
-            return;
-        }
-        stk.put(sp++, S.flat_off + (uint32_t)__builtin_ctz(cand));
-        cand &= cand - 1u;
-    }
-    // A round's first node step: the instrumented and the GRID walks keep the one-piece step (its counters tell scanned leaves from
-    // walked TLAS nodes; its TLAS level is not a stack level)
-    PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
-        if constexpr (STATS || GRID) {
-            node_step(S, stk, cnt);
-        } else {
-            floor_step(S, stk);
-            if (mode == PBRS_WALK_NODE) node_step_fast(S, stk, cnt);
-        }
-    }
     // A round's FURTHER node steps (kernels.h, PBRS_MORE_NODE_STEPS): the common case only — a pending entry of the tree the lane is
     // in is popped and tested.  A lane whose stack is down to the floor of its tree (the instance used up, the next scanned TLAS
-    // leaf, the end of the walk) sits the step out and lets the round's first step, which has the code for all that, take it: the
+    // leaf, the end of the walk) sits the step out and lets the round's first step (node_step), which has the code for all that, take it: the
     // second and third copies of the step carry a third fewer scalar instructions (exec-mask bookkeeping of branches that nearly
     // every execution took for one or two lanes).
     PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
-        if (GRID || sp == (in_blas ? blas_base : 0) || !C.fast) {  // (a ray on the literal divisions: the first step's, too)
-            if (GRID) node_step(S, stk, cnt);
-            return;
-        }
+        if (sp == (in_blas ? blas_base : 0) || !C.fast) return;  // (a ray on the literal divisions: the first step's, too)
         PBRS_TP(0);
         const uint32_t ni = stk.get(--sp);
         if (STATS) {
@@ -658,14 +572,6 @@ struct ClosestWalk {
         // walk is back at this stack level.  A mesh continues in the node state with its BLAS root, an IsolatedTriangle
         // is one held triangle record; either way the candidate (mt, ...) meets `best` at the exit above (or at retire
         // time, finish).  An analytic shape is visited here and now (analytic_visit).
-        if constexpr (GRID) {
-            if (cur_inst & PBRS_BOX_PENDING) {  // a scanned TLAS leaf at its turn: the reference's box test, with the extent of this moment
-                const pbrs_node leaf = load_node(S.nodes + S.flat_off + (cur_inst & ~PBRS_BOX_PENDING));
-                if (!slab_rs(leaf, exact_space(C), lt)) return;  // (mode is NODE again: the next scanned leaf)
-                cur_inst = leaf.a;
-                inst_info = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
-            }
-        }
         const pbrs_instance& in = S.inst[cur_inst];
         CNT(instances);
         PBRS_TP(6);
@@ -684,11 +590,6 @@ struct ClosestWalk {
         if (kind == PBRS_SHAPE_MESH) {
             inst_info = kind | (H.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
             stk.put(sp++, H.blas_root);
-            if constexpr (GRID) {
-                // onto the grid of this mesh; a ray too far from it walks the mesh's full nodes with the literal divisions (always
-                // the reference's test; it stays on them until a boundary step rebuilds its space)
-                if (C.fast && !G.set(C, S.cframes[cur_inst])) C.fast = false;
-            }
         } else if (kind == PBRS_SHAPE_TRIANGLE) {
             // IsolatedTriangle (simple.rs:417-426): one triangle record, no boxes, no shading frame
             inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
@@ -746,19 +647,6 @@ struct ClosestWalk {
 
     // The held leaves of the whole wave in one execution (TriShare); every lane of the wave calls this together.
     PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
-        if constexpr (GRID) {
-            if (mode == PBRS_WALK_LEAF && leaf_end == 0xffffffffu) {  // a leaf whose record passed: the reference's test of its own box
-                const pbrs_node node = load_node(S.nodes + leaf_a);
-                leaf_a = node.a;
-                leaf_end = node.a;
-                if (slab_rs(node, exact_space(C), lt)) {
-                    PBRS_TP(4);
-                    leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
-                    if (leaf_end == leaf_a) lt = mt;  // an empty leaf still runs blas.rs:468
-                }
-                if (leaf_end == leaf_a) mode = sp == blas_base ? exit_mode() : PBRS_WALK_NODE;
-            }
-        }
         const bool tri_leaf = mode == PBRS_WALK_LEAF;  // analytic shapes never wait here (analytic_visit)
         TriShare sh;
         sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
@@ -830,7 +718,7 @@ struct ClosestWalk {
 // the visiting order cannot change the answer and nothing is carried between instances, so BLAS children
 // are visited near-first (by the sign of the ray direction on the split axis), which reaches an occluder
 // sooner than the reference's left-first recursion.
-template <bool STATS, uint32_t FEAT, bool GRID = false>  // GRID: see ClosestWalk
+template <bool STATS, uint32_t FEAT>
 struct AnyWalk {
     RaySpace C;
     float t_max;
@@ -839,9 +727,7 @@ struct AnyWalk {
     uint32_t cand;  // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, occluded, moved;  // moved: C is not the world ray (inst_kind bit 8: only its origin differs)
     uint32_t mode;
-    typename GridSel<GRID>::type G;
     PBRS_TP_FIELDS
-    PD void forget_reciprocals() { C.nr = gray(0.0f); }
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         C = make_space(o, d, S.fast_slab != 0);
@@ -898,29 +784,6 @@ struct AnyWalk {
             return;
         }
         const uint32_t ni = stk.get(--sp);
-        if constexpr (GRID) {
-            if (in_blas && C.fast) {  // a mesh's node through its compressed record (ClosestWalk::node_step)
-                PBRS_TP(1);
-                const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[ni];
-                if (!cnode_filter(pbrs_cnode{raw.x, raw.y, raw.z, raw.w}, G, t_max)) {
-                    PBRS_TP(2);
-                    if (PBRS_EARLY_OUT && sp == blas_base) mode = exit_mode();
-                    return;
-                }
-                if (!(raw.w & PBRS_CNODE_LEAF)) {
-                    const bool left_first = (__float_as_uint(comp(G.A, (int)((raw.w >> 29) & 3u))) >> 31) == 0u;
-                    const uint32_t left = ni + 1u, right = raw.w & PBRS_CNODE_CHILD_MASK;
-                    stk.put(sp++, left_first ? right : left);
-                    stk.put(sp++, left_first ? left : right);
-                } else {
-                    PBRS_TP(3);
-                    leaf_a = ni;
-                    leaf_end = 0xffffffffu;
-                    mode = PBRS_WALK_LEAF;
-                }
-                return;
-            }
-        }
         const pbrs_node node = load_node_at(S.nodes, ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
@@ -949,36 +812,8 @@ struct AnyWalk {
             mode = PBRS_WALK_XFER;
         }
     }
-    PD void floor_step(const DevScene& S, LaneStack stk) {  // see ClosestWalk::floor_step; a scanned leaf's box has passed already
-        if (in_blas) {
-            if (sp == blas_base) mode = exit_mode();
-            return;
-        }
-        if (sp != 0) return;
-        if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || cand == 0u) {
-            mode = PBRS_WALK_DONE;
-            return;
-        }
-        const uint32_t k = (uint32_t)__builtin_ctz(cand);
-        cand &= cand - 1u;
-        const pbrs_node leaf = load_node(S.nodes + S.flat_off + k);
-        leaf_a = leaf.a;
-        inst_kind = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
-        mode = PBRS_WALK_XFER;
-    }
-    PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
-        if constexpr (STATS || GRID) {
-            node_step(S, stk, cnt);
-        } else {
-            floor_step(S, stk);
-            if (mode == PBRS_WALK_NODE) node_step_fast(S, stk, cnt);
-        }
-    }
     PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {  // see ClosestWalk::node_step_fast
-        if (GRID || sp == (in_blas ? blas_base : 0) || !C.fast) {
-            if (GRID) node_step(S, stk, cnt);
-            return;
-        }
+        if (sp == (in_blas ? blas_base : 0) || !C.fast) return;
         PBRS_TP(0);
         const uint32_t ni = stk.get(--sp);
         const pbrs_node node = load_node_at(S.nodes, ni);
@@ -1034,9 +869,6 @@ struct AnyWalk {
         if (inst_kind == PBRS_SHAPE_MESH) {
             if (space == PBRS_SPACE_TRANSLATED) inst_kind |= 0x100u;  // only meshes: the tests below read the kind before or mask it
             stk.put(sp++, H.blas_root);
-            if constexpr (GRID) {
-                if (C.fast && !G.set(C, S.cframes[leaf_a])) C.fast = false;  // (ClosestWalk::xfer_step)
-            }
         } else if (inst_kind == PBRS_SHAPE_TRIANGLE) {  // IsolatedTriangle::occludes (simple.rs:428-433): its triangle record
             leaf_a = H.blas_root;
             leaf_end = H.blas_root + 1u;
@@ -1046,15 +878,6 @@ struct AnyWalk {
     // The held leaves of the whole wave in one execution (TriShare); every lane of the wave calls this together.
     // `intersect_bvh_pred` stops at a leaf's first occluder (blas.rs:478-495): the owner counts its triangles up to that one.
     PD void leaf_wave(const DevScene& S, Cnt<STATS>& cnt) {
-        if constexpr (GRID) {
-            if (mode == PBRS_WALK_LEAF && leaf_end == 0xffffffffu) {  // the reference's test of the leaf's own box (intersect_bvh_pred, blas.rs:478-495)
-                const pbrs_node node = load_node(S.nodes + leaf_a);
-                leaf_a = node.a;
-                leaf_end = slab_rs(node, exact_space(C), t_max) ? node.a + (node.b & ~PBRS_LEAF_FLAG) : node.a;
-                if (leaf_end != leaf_a) PBRS_TP(4);
-                if (leaf_end == leaf_a) mode = sp == blas_base ? exit_mode() : PBRS_WALK_NODE;
-            }
-        }
         const bool tri_leaf = mode == PBRS_WALK_LEAF;  // analytic shapes never wait here (analytic_visit)
         TriShare sh;
         sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
@@ -1136,384 +959,24 @@ struct AnyWalk {
 // the binary-walk kernel (kernels.h).
 #define PBRS_WALK_SLOW 6u
 #define PBRS_LEAF_UNVERIFIED 0xffffffffu
-// ARITY 4: four-wide nodes (DevScene::wnodes, an instance's root in pad[1]); ARITY 2: pair nodes (wide.h; the launch passes them
-// through the same DevScene fields: wnodes = the pair nodes, wide_cap = their stack rows, wroot[instance] = the root's pair node)
-template <uint32_t ARITY>
-struct WRaySel {
-    typedef WideRay type;
-};
-template <>
-struct WRaySel<2u> {
-    typedef PairRay type;
-};
-template <>
-struct WRaySel<1u> {  // the binary tree itself through its compressed records (wide.h): DevScene::cnodes, ::cframes
-    typedef CRay type;
-};
-// One node step on compressed records: node e against the extent; `next`: the child to take from the register (the other one is
-// pushed), PBRS_WREF_LEAF | e for a leaf whose record passed, PBRS_WREF_NONE for a record that failed; `false`: the push would not fit.
-PD bool cnode_step(const DevScene& S, uint32_t e, const RaySpace& C, const CRay& W, float ext, LaneStack stk, int& sp, uint32_t& next) {
-    const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[e];
-    const pbrs_cnode n{raw.x, raw.y, raw.z, raw.w};
-    next = PBRS_WREF_NONE;
-    if (!cnode_filter(n, W, ext)) return true;
-    if (n.link & PBRS_CNODE_LEAF) {
-        next = PBRS_WREF_LEAF | e;
-        return true;
-    }
-    if (sp + 1 > (int)S.wide_cap) return false;
-    // blas.rs:456-466: the left child first iff ray.dir[axis] > 0.  A = step * (1 / dir) carries the direction's sign (a zero step
-    // gives a signed zero), which keeps the direction itself out of the node step's registers.
-    const bool left_first = (__float_as_uint(comp(W.A, (int)((n.link >> 29) & 3u))) >> 31) == 0u;
-    const uint32_t left = e + 1u, right = n.link & PBRS_CNODE_CHILD_MASK;
-    stk.put(sp++, left_first ? right : left);
-    next = left_first ? left : right;
-    return true;
-}
-template <uint32_t ARITY>
-PD uint32_t wide_root_of(const DevScene& S, const InstHead& H, uint32_t inst) {
-    return ARITY == 2u ? S.wroot[inst] : H.wide_root;
-}
-// One node step's test and pushes on pair nodes: the survivor visited first is returned (PBRS_WREF_NONE: neither passed),
-// the other one pushed; `false`: the push might not fit (the binary walk takes the ray).
-PD bool pair_node(const DevScene& S, uint32_t e, const RaySpace& C, const PairRay& W, float ext, LaneStack stk, int& sp, uint32_t& next) {
-    const PairTest t = pair_test(S.wnodes, e, C, W, ext);
-    next = t.pf ? t.first : t.ps ? t.second : PBRS_WREF_NONE;
-    if (t.pf && t.ps) {
-        if (sp + 1 > (int)S.wide_cap) return false;
-        stk.put(sp++, t.second);
-    }
-    return true;
-}
-template <uint32_t FEAT, uint32_t ARITY = 4u>
-struct ClosestWalkW : ClosestWalk<false, FEAT> {
-    using B = ClosestWalk<false, FEAT>;
-    using B::C; using B::best; using B::t_max; using B::lt; using B::mt; using B::mb1; using B::mb2; using B::mprim; using B::cur_inst;
-    using B::inst_info; using B::leaf_a; using B::leaf_end; using B::sp; using B::blas_base; using B::cand; using B::in_blas; using B::moved; using B::mode;
-    typename WRaySel<ARITY>::type W;
-    uint32_t cur;  // wide node to take next (the nearest survivor of the last node step), or PBRS_WREF_NONE
-    // the lane's space with its reciprocals, for the reference's own test: the wide and pair walks keep them (as RN(1 / d)) for their filter
-    PD RaySpace exact_w() const {
-        if constexpr (ARITY == 1u) {
-            return exact_space(C);
-        } else {
-            RaySpace E = C;
-            E.nr = -W.r32;
-            return E;
-        }
-    }
-    // A BLAS leaf held UNVERIFIED is (leaf_a = its node index, leaf_end = PBRS_LEAF_UNVERIFIED); the scanned TLAS leaf about to be
-    // entered travels in leaf_a too.  The lane's column of the block's entry-distance table sits after the stack rows:
-    // row DevScene::wide_cap + k for scanned leaf k.  A wide walk is never below a TLAS entry (the TLAS is scanned): blas_base = 0.
-
-    PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
-        B::start(S, o, d, tmax, stk);
-        cur = PBRS_WREF_NONE;
-        if constexpr (ARITY != 1u) W.set(C);  // (compressed records: per mesh, at its boundary)
-        if (mode != PBRS_WALK_SCAN) mode = PBRS_WALK_SLOW;  // not on the division-free test: the binary walk's ray
-    }
-    PD void scan_wave(const DevScene& S, LaneStack stk) {
-        float* tl_block = reinterpret_cast<float*>(stk.base) - (threadIdx.x & (PBRS_TRAVERSAL_BLOCK - 1)) + S.wide_cap * PBRS_TRAVERSAL_BLOCK;
-        const uint32_t mine = flat_scan_tlow(S, mode == PBRS_WALK_SCAN, C, tl_block);
-        if (mode == PBRS_WALK_SCAN) {
-            cand = mine;
-            mode = PBRS_WALK_NODE;
-        }
-    }
-    PD uint32_t after_leaf() const { return sp == 0 ? B::exit_mode() : PBRS_WALK_NODE; }
-    PD void hold_leaf(uint32_t ref) {
-        leaf_a = ref & PBRS_WREF_INDEX;
-        leaf_end = PBRS_LEAF_UNVERIFIED;
-        mode = PBRS_WALK_LEAF;
-    }
-    // The space's own reciprocals are not state of a wide walk (exact_w): dropping them at the end of every loop round keeps three
-    // registers from living across it (the shared scan reads them from every lane of the wave, fresh or not).
-    PD void forget_reciprocals() { C.nr = gray(0.0f); }
-    // The node step over compressed records, written for the instruction count of its common path (one load, one filter, selects):
-    // everything rare — the next scanned TLAS leaf, the end of a mesh — sits behind the one test for an empty stack.
-    PD void node_step_c(const DevScene& S, LaneStack stk) {
-        uint32_t e = cur;
-        if (e == PBRS_WREF_NONE) {
-            if (sp == 0) {  // (a wide walk is never below a TLAS entry: at the TLAS level the stack is empty)
-                if (in_blas) {
-                    mode = B::exit_mode();
-                } else if (cand == 0u) {
-                    mode = PBRS_WALK_DONE;
-                } else {  // the next scanned leaf whose box the reference's test passes NOW (t_low <= min(hi_el, t_max))
-                    const uint32_t k = (uint32_t)__builtin_ctz(cand);
-                    cand &= cand - 1u;
-                    if (__uint_as_float(stk.get((int)(S.wide_cap + k))) <= t_max) {
-                        leaf_a = k;
-                        mode = PBRS_WALK_XFER;
-                    }
-                }
-                return;
-            }
-            e = stk.get(--sp);
-        }
-        PBRS_TP(1);
-        const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[e];
-        const bool pass = cnode_filter(pbrs_cnode{raw.x, raw.y, raw.z, raw.w}, W, lt);
-        const bool leaf = (raw.w & PBRS_CNODE_LEAF) != 0u;
-        const bool fits = sp < (int)S.wide_cap;
-        const bool inner = pass && !leaf && fits;
-        // blas.rs:456-466: the left child first iff ray.dir[axis] > 0; A = step * (1 / dir) carries the direction's sign (a zero
-        // step gives a signed zero), which keeps the direction itself out of this step's registers
-        const bool left_first = (__float_as_uint(comp(W.A, (int)((raw.w >> 29) & 3u))) >> 31) == 0u;
-        const uint32_t left = e + 1u, right = raw.w & PBRS_CNODE_CHILD_MASK;
-        if (inner) stk.put(sp, left_first ? right : left);
-        sp += inner ? 1 : 0;
-        cur = inner ? (left_first ? left : right) : PBRS_WREF_NONE;
-        lt = inner ? mt : lt;  // blas.rs:468: once a node has passed, the cloned ray's extent follows outer_hit (the root saw the incoming one)
-        if (pass && leaf) hold_leaf(e);
-        if (pass && !leaf && !fits) mode = PBRS_WALK_SLOW;  // the binary walk takes this ray from its start
-        if (!pass) {
-            PBRS_TP(2);
-            if (sp == 0) mode = B::exit_mode();
-        }
-    }
-    // a round's further node steps: a lane with nothing to take from its register or its stack (the next scanned TLAS leaf, the end
-    // of a mesh or of the walk: the first step's business) sits them out — see ClosestWalk::node_step_fast
-    PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
-        if (cur == PBRS_WREF_NONE && sp == 0) return;
-        node_step(S, stk, cnt);
-    }
-    PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
-    PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
-        PBRS_TP(0);
-        if constexpr (ARITY == 1u) {
-            node_step_c(S, stk);
-            return;
-        }
-        uint32_t e = cur;
-        if (e == PBRS_WREF_NONE) {
-            if (!in_blas) {  // TLAS level: the next scanned leaf whose box the reference's test passes NOW (t_low <= min(hi_el, t_max))
-                if (cand == 0u) {
-                    mode = PBRS_WALK_DONE;
-                    return;
-                }
-                const uint32_t k = (uint32_t)__builtin_ctz(cand);
-                cand &= cand - 1u;
-                if (__uint_as_float(stk.get((int)(S.wide_cap + k))) <= t_max) {
-                    leaf_a = k;
-                    mode = PBRS_WALK_XFER;
-                }
-                return;
-            }
-            if (sp == 0) {
-                mode = B::exit_mode();
-                return;
-            }
-            e = stk.get(--sp);
-        }
-        cur = PBRS_WREF_NONE;
-        if (e & PBRS_WREF_LEAF) {
-            hold_leaf(e);
-            return;
-        }
-        PBRS_TP(1);
-        if constexpr (ARITY == 1u) {
-            uint32_t next;
-            if (!cnode_step(S, e, C, W, lt, stk, sp, next)) {
-                mode = PBRS_WALK_SLOW;
-                return;
-            }
-            if (next == PBRS_WREF_NONE) {
-                PBRS_TP(2);
-                if (sp == 0) mode = B::exit_mode();
-            } else if (next & PBRS_WREF_LEAF) {
-                hold_leaf(next);
-            } else {
-                cur = next;
-                lt = mt;  // blas.rs:468: after a node passed, the cloned ray's extent follows outer_hit (the root saw the incoming one)
-            }
-        } else if constexpr (ARITY == 2u) {
-            uint32_t first;
-            if (!pair_node(S, e, C, W, lt, stk, sp, first)) {
-                mode = PBRS_WALK_SLOW;
-                return;
-            }
-            if (first == PBRS_WREF_NONE) {
-                PBRS_TP(2);
-                if (sp == 0) mode = B::exit_mode();
-            } else if (first & PBRS_WREF_LEAF) {
-                hold_leaf(first);
-            } else {
-                cur = first;
-            }
-        } else {
-            const WideTest t = wide_test(S.wnodes, e, C, W, lt);  // inside a mesh lt == mt at every node (blas.rs:468), after the root
-            if (t.pass == 0u) {
-                PBRS_TP(2);
-                if (sp == 0) mode = B::exit_mode();
-                return;
-            }
-            if (sp + 3 > (int)S.wide_cap) {  // the pushes below might not fit: the binary walk takes this ray from its start
-                mode = PBRS_WALK_SLOW;
-                return;
-            }
-            const uint32_t first = wide_push(wide_order(t, C.d), stk, sp);  // the reference's order; its first is taken next, from the register
-            if (first & PBRS_WREF_LEAF) hold_leaf(first);
-            else cur = first;
-        }
-    }
-    PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
-        if (in_blas) {
-            // the way out: Instance::intersect returns (bvh.rs:82-95) — ClosestWalk::xfer_step's first branch, restated here so that its
-            // second one (the way in, which this walk has its own version of below) is not compiled into this kernel twice: with both
-            // copies the allocator spilled some 40 registers around them
-            const bool rebuilt = moved && !(inst_info & 0x40000000u);  // leave_instance rebuilds the world ray, reciprocals included
-            mode = PBRS_WALK_NODE;
-            in_blas = false;
-            leave_instance(S, stk, !moved ? PBRS_SPACE_WORLD : (inst_info & 0x40000000u) ? PBRS_SPACE_TRANSLATED : PBRS_SPACE_MOVED, C);
-            B::meet_best(cnt);
-            lt = t_max;  // back in the TLAS
-            if constexpr (ARITY != 1u)
-                if (rebuilt) W.set(C);
-            return;
-        }
-        mode = PBRS_WALK_NODE;
-        PBRS_TP(6);
-        const pbrs_node leaf = load_node(S.nodes + S.flat_off + leaf_a);  // its box passed at this moment (node_step)
-        cur_inst = leaf.a;
-        const uint32_t kind = (leaf.b >> PBRS_TLAS_LEAF_KIND_SHIFT) & 7u;
-        inst_info = kind;
-        const pbrs_instance& in = S.inst[cur_inst];
-        if ((FEAT & PBRS_FEAT_ANALYTIC) && kind != PBRS_SHAPE_MESH && kind != PBRS_SHAPE_TRIANGLE) {
-            B::analytic_visit(S, in, kind, cnt);
-            return;
-        }
-        const InstHead H = load_inst_head(in);
-        const uint32_t space = enter_instance(S, in, H.flags, C, kind == PBRS_SHAPE_MESH, stk);
-        moved = space != PBRS_SPACE_WORLD;
-        in_blas = true;
-        blas_base = 0;
-        lt = t_max;
-        mt = pn_inf();
-        if (kind == PBRS_SHAPE_MESH) {
-            if (!C.fast) {  // the instance's space is outside the guarded range
-                mode = PBRS_WALK_SLOW;
-                return;
-            }
-            inst_info = kind | (H.mesh_flags << 3) | (space == PBRS_SPACE_TRANSLATED ? 0x40000000u : 0u);
-            if constexpr (ARITY == 1u) {  // the ray on the grid of this mesh; the root's record is tested like any other, against the incoming extent
-                if (!W.set(C, S.cframes[cur_inst])) mode = PBRS_WALK_SLOW;  // too far from this mesh's grid: the binary walk's ray
-                cur = H.blas_root;
-                return;
-            }
-            if constexpr (ARITY != 1u)
-                if (space == PBRS_SPACE_MOVED) W.set(C);  // a new direction (make_space has just computed its reciprocals); else the world's stands
-            const uint32_t wroot = wide_root_of<ARITY>(S, H, cur_inst);
-            if (wroot == PBRS_WREF_NONE) {  // the mesh is one leaf: its box is tested, against the incoming extent, with its triangles
-                hold_leaf(H.blas_root);
-                return;
-            }
-            // the root against the incoming extent (blas.rs:441 at the first pop), the reference's test; then lt = mt (:468)
-            if (!slab_rs(load_node(S.nodes + H.blas_root), exact_w(), lt)) {
-                mode = B::exit_mode();
-                return;
-            }
-            lt = mt;
-            cur = wroot;
-        } else if (kind == PBRS_SHAPE_TRIANGLE) {
-            inst_info = kind | (PBRS_MESH_SHADING_OK_MASK << 3);
-            leaf_a = H.blas_root;
-            leaf_end = H.blas_root + 1u;
-            mode = PBRS_WALK_LEAF;
-        }
-    }
-    // The held leaves of the whole wave: first the reference's box test for the unverified ones, then ClosestWalk::leaf_wave's
-    // shared triangle tests (same values, same order).
-    PD void leaf_wave(const DevScene& S, Cnt<false>& cnt) {
-        if (mode == PBRS_WALK_LEAF && leaf_end == PBRS_LEAF_UNVERIFIED) {
-            PBRS_TP(3);
-            const pbrs_node node = load_node(S.nodes + leaf_a);
-            leaf_a = node.a;
-            leaf_end = node.a;
-            if (slab_rs(node, exact_w(), lt)) {
-                PBRS_TP(4);
-                leaf_end = node.a + (node.b & ~PBRS_LEAF_FLAG);
-                if (leaf_end == leaf_a) lt = mt;  // an empty leaf still runs blas.rs:468
-            }
-            if (leaf_end == leaf_a) mode = after_leaf();
-        }
-        const bool tri_leaf = mode == PBRS_WALK_LEAF;
-        TriShare sh;
-        sh.build(tri_leaf ? leaf_end - leaf_a : 0u);
-        if (sh.has[0] == 0) return;
-        const f3 ho = sh.from_owner(C.o), hd = sh.from_owner(C.d);
-        const float hlt = sh.from_owner(lt);
-        const uint32_t hti = sh.from_owner(leaf_a) + sh.k();
-        const uint32_t hinfo = (FEAT & PBRS_FEAT_SHADING_CHECK) ? sh.from_owner(inst_info) : 0u;
-        const float hmt = (FEAT & PBRS_FEAT_SHADING_CHECK) ? sh.from_owner(mt) : 0.0f;
-        float rt = pn_inf(), rb1 = 0.0f, rb2 = 0.0f;
-        if (sh.helper()) {
-            PBRS_TP(5);
-            pbrs_tri_verts tv = load_tri(S.tv + hti);
-            TriHit h;
-            constexpr bool need_bary = (FEAT & PBRS_FEAT_SHADING_CHECK) != 0u;
-            bool hit = mesh_tri_hit_t<need_bary>(tv, ho, hd, hlt, S.fast_slab != 0u, h);
-            if ((FEAT & PBRS_FEAT_SHADING_CHECK) && hit && h.t < hmt && !((hinfo >> 3) & PBRS_MESH_SHADING_OK_MASK)) {
-                f3 n, dpdu;
-                hit = mesh_tri_shading(tv, S.ts[hti], hd, h, n, dpdu);
-            }
-            if (hit) {
-                rt = h.t;
-                rb1 = h.b1;
-                rb2 = h.b2;
-            }
-        }
-        uint32_t win = 0xffffffffu, win_tri = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            if (sh.has[j] == 0) break;
-            const uint32_t at = sh.pos(j);
-            const float t = sh.from_helper(at, rt);
-            if (j < sh.cnt && t < mt) {
-                mt = t;
-                win = at;
-                win_tri = leaf_a + j;
-            }
-        }
-        if (__ballot(win != 0xffffffffu)) {
-            const float b1 = sh.from_helper(win, rb1), b2 = sh.from_helper(win, rb2);
-            if (win != 0xffffffffu) {
-                mprim = (inst_info & 7u) == PBRS_SHAPE_MESH ? win_tri : 0u;
-                mb1 = b1;
-                mb2 = b2;
-            }
-        }
-        if (tri_leaf) {
-            leaf_a += sh.cnt;
-            if (leaf_a == leaf_end) {
-                mode = after_leaf();
-                lt = mt;
-            }
-        }
-    }
-};
-
-template <uint32_t FEAT, uint32_t ARITY = 4u>
+template <uint32_t FEAT>
 struct AnyWalkW : AnyWalk<false, FEAT> {
     using B = AnyWalk<false, FEAT>;
     using B::C; using B::t_max; using B::leaf_a; using B::leaf_end; using B::inst_kind; using B::sp; using B::blas_base; using B::cand; using B::in_blas;
     using B::occluded; using B::moved; using B::mode;
-    typename WRaySel<ARITY>::type W;
+    WideRay W;
     uint32_t cur;
-    PD RaySpace exact_w() const {  // see ClosestWalkW::exact_w
-        if constexpr (ARITY == 1u) {
-            return exact_space(C);
-        } else {
-            RaySpace E = C;
-            E.nr = -W.r32;
-            return E;
-        }
+    // the lane's space with its reciprocals, for the reference's own test: the wide walk keeps them (as RN(1 / d)) for its filter
+    PD RaySpace exact_w() const {
+        RaySpace E = C;
+        E.nr = -W.r32;
+        return E;
     }
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         B::start(S, o, d, tmax, stk);
         cur = PBRS_WREF_NONE;
-        if constexpr (ARITY != 1u) W.set(C);
+        W.set(C);
         if (mode != PBRS_WALK_SCAN) mode = PBRS_WALK_SLOW;
     }
     PD void scan_wave(const DevScene& S, LaneStack) {
@@ -1527,54 +990,14 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
         mode = PBRS_WALK_LEAF;
     }
     PD void forget_reciprocals() { C.nr = gray(0.0f); }
-    PD void node_step_c(const DevScene& S, LaneStack stk) {  // see ClosestWalkW::node_step_c
-        uint32_t e = cur;
-        if (e == PBRS_WREF_NONE) {
-            if (sp == 0) {
-                if (in_blas) {
-                    mode = B::exit_mode();
-                } else if (cand == 0u) {
-                    mode = PBRS_WALK_DONE;
-                } else {  // the next leaf that passed the scan (the reference's test: the extent never changes)
-                    leaf_a = (uint32_t)__builtin_ctz(cand);
-                    cand &= cand - 1u;
-                    mode = PBRS_WALK_XFER;
-                }
-                return;
-            }
-            e = stk.get(--sp);
-        }
-        PBRS_TP(1);
-        const uint4 raw = reinterpret_cast<const uint4*>(S.cnodes)[e];
-        const bool pass = cnode_filter(pbrs_cnode{raw.x, raw.y, raw.z, raw.w}, W, t_max);
-        const bool leaf = (raw.w & PBRS_CNODE_LEAF) != 0u;
-        const bool fits = sp < (int)S.wide_cap;
-        const bool inner = pass && !leaf && fits;
-        const bool left_first = (__float_as_uint(comp(W.A, (int)((raw.w >> 29) & 3u))) >> 31) == 0u;
-        const uint32_t left = e + 1u, right = raw.w & PBRS_CNODE_CHILD_MASK;
-        if (inner) stk.put(sp, left_first ? right : left);
-        sp += inner ? 1 : 0;
-        cur = inner ? (left_first ? left : right) : PBRS_WREF_NONE;
-        if (pass && leaf) hold_leaf(e);
-        if (pass && !leaf && !fits) mode = PBRS_WALK_SLOW;
-        if (!pass) {
-            PBRS_TP(2);
-            if (sp == 0) mode = B::exit_mode();
-        }
-    }
     // a round's further node steps: a lane with nothing to take from its register or its stack (the next scanned TLAS leaf, the end
     // of a mesh or of the walk: the first step's business) sits them out — see ClosestWalk::node_step_fast
     PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
         if (cur == PBRS_WREF_NONE && sp == 0) return;
         node_step(S, stk, cnt);
     }
-    PD void first_node_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) { node_step(S, stk, cnt); }
     PD void node_step(const DevScene& S, LaneStack stk, Cnt<false>&) {
         PBRS_TP(0);
-        if constexpr (ARITY == 1u) {
-            node_step_c(S, stk);
-            return;
-        }
         uint32_t e = cur;
         if (e == PBRS_WREF_NONE) {
             if (!in_blas) {  // TLAS level: the next leaf that passed the scan (the reference's test: the extent never changes)
@@ -1599,49 +1022,19 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             return;
         }
         PBRS_TP(1);
-        if constexpr (ARITY == 1u) {
-            uint32_t next;
-            if (!cnode_step(S, e, C, W, t_max, stk, sp, next)) {
-                mode = PBRS_WALK_SLOW;
-                return;
-            }
-            if (next == PBRS_WREF_NONE) {
-                PBRS_TP(2);
-                if (sp == 0) mode = B::exit_mode();
-            } else if (next & PBRS_WREF_LEAF) {
-                hold_leaf(next);
-            } else {
-                cur = next;
-            }
-        } else if constexpr (ARITY == 2u) {
-            uint32_t first;
-            if (!pair_node(S, e, C, W, t_max, stk, sp, first)) {
-                mode = PBRS_WALK_SLOW;
-                return;
-            }
-            if (first == PBRS_WREF_NONE) {
-                PBRS_TP(2);
-                if (sp == 0) mode = B::exit_mode();
-            } else if (first & PBRS_WREF_LEAF) {
-                hold_leaf(first);
-            } else {
-                cur = first;
-            }
-        } else {
-            const WideTest t = wide_test(S.wnodes, e, C, W, t_max);
-            if (t.pass == 0u) {
-                PBRS_TP(2);
-                if (sp == 0) mode = B::exit_mode();
-                return;
-            }
-            if (sp + 3 > (int)S.wide_cap) {
-                mode = PBRS_WALK_SLOW;
-                return;
-            }
-            const uint32_t first = wide_push(wide_order_any(t, C.d), stk, sp);
-            if (first & PBRS_WREF_LEAF) hold_leaf(first);
-            else cur = first;
+        const WideTest t = wide_test(S.wnodes, e, C, W, t_max);
+        if (t.pass == 0u) {
+            PBRS_TP(2);
+            if (sp == 0) mode = B::exit_mode();
+            return;
         }
+        if (sp + 3 > (int)S.wide_cap) {
+            mode = PBRS_WALK_SLOW;
+            return;
+        }
+        const uint32_t first = wide_push(wide_order_any(t, C.d), stk, sp);
+        if (first & PBRS_WREF_LEAF) hold_leaf(first);
+        else cur = first;
     }
     PD void xfer_step(const DevScene& S, LaneStack stk, Cnt<false>& cnt) {
         if (in_blas) {
@@ -1649,8 +1042,7 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
             mode = PBRS_WALK_NODE;
             in_blas = false;
             leave_instance(S, stk, !moved ? PBRS_SPACE_WORLD : (inst_kind & 0x100u) ? PBRS_SPACE_TRANSLATED : PBRS_SPACE_MOVED, C);
-            if constexpr (ARITY != 1u)
-                if (rebuilt) W.set(C);
+            if (rebuilt) W.set(C);
             return;
         }
         mode = PBRS_WALK_NODE;
@@ -1674,14 +1066,8 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
                 return;
             }
             if (space == PBRS_SPACE_TRANSLATED) inst_kind |= 0x100u;
-            if constexpr (ARITY == 1u) {
-                if (!W.set(C, S.cframes[leaf_a])) mode = PBRS_WALK_SLOW;
-                cur = H.blas_root;
-                return;
-            }
-            if constexpr (ARITY != 1u)
-                if (space == PBRS_SPACE_MOVED) W.set(C);
-            const uint32_t wroot = wide_root_of<ARITY>(S, H, leaf_a);
+            if (space == PBRS_SPACE_MOVED) W.set(C);  // a new direction (make_space has just computed its reciprocals); else the world's stands
+            const uint32_t wroot = H.wide_root;
             if (wroot == PBRS_WREF_NONE) {
                 hold_leaf(H.blas_root);
                 return;
@@ -1767,29 +1153,9 @@ PD bool tlas_any(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneSt
     }
     return w.occluded;
 }
-// The same through the wide walks (parity harness of the kernels that walk four-wide nodes): rays those walks refuse fall back
-// to the binary walk, as they do in the pipeline.  The block's entry-distance table sits after DevScene::wide_cap stack rows.
-PD void tlas_closest_wide(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneStack stk, Hit& best) {
-    Cnt<false> cnt;
-    ClosestWalkW<PBRS_FEAT_ALL> w;
-    w.start(S, o, d, t_max, stk);
-    if (!active) w.mode = PBRS_WALK_DONE;
-    w.scan_wave(S, stk);
-    while (__ballot(w.mode == PBRS_WALK_NODE || w.mode == PBRS_WALK_LEAF || w.mode == PBRS_WALK_XFER)) {
-        if (w.mode == PBRS_WALK_XFER) w.xfer_step(S, stk, cnt);
-        if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
-        if (__ballot(w.mode == PBRS_WALK_LEAF)) w.leaf_wave(S, cnt);
-    }
-    const bool slow = w.mode == PBRS_WALK_SLOW;
-    w.finish(cnt);
-    best = w.best;
-    if (__ballot(slow)) {
-        Hit b2;
-        tlas_closest<false>(S, active && slow, o, d, t_max, stk, b2, cnt);
-        if (slow) best = b2;
-    }
-}
-PD bool tlas_any_wide(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneStack stk) {
+// The same through the four-wide any-hit walk (parity harness of k_shadow's wide kernels): rays that walk refuses fall back to the
+// binary walk, as they do in the pipeline.
+PD bool tlas_any_wide(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneStack stk, bool& slow) {
     Cnt<false> cnt;
     AnyWalkW<PBRS_FEAT_ALL> w;
     w.start(S, o, d, t_max, stk);
@@ -1800,7 +1166,7 @@ PD bool tlas_any_wide(const DevScene& S, bool active, f3 o, f3 d, float t_max, L
         if (w.mode == PBRS_WALK_NODE) w.node_step(S, stk, cnt);
         if (__ballot(w.mode == PBRS_WALK_LEAF)) w.leaf_wave(S, cnt);
     }
-    const bool slow = w.mode == PBRS_WALK_SLOW;
+    slow = w.mode == PBRS_WALK_SLOW;  // refused (outside the guarded range, or the stack would not fit): the binary walk's ray, as in the pipeline
     bool occ = w.occluded;
     if (__ballot(slow)) {
         const bool o2 = tlas_any<false>(S, active && slow, o, d, t_max, stk, cnt);

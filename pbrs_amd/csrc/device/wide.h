@@ -1,4 +1,4 @@
-// device/wide.h — four-wide BVH nodes for the BLAS walks of k_extend / k_shadow (round 3).
+// device/wide.h — four-wide BVH nodes for the BLAS walk of k_shadow (round 3; the closest-hit walk over them: device/experimental/).
 //
 // What the reference's traversal DEFINES, for a ray on the division-free box test (no NaN quotients, traverse.h), is small:
 //   * closest hit in a mesh (shape/src/blas.rs:422-476): the leaves are taken in the order of the near-first depth-first walk
@@ -43,9 +43,6 @@ struct pbrs_wnode {
 #ifndef PBRS_WIDE_MIN_LEVELS
 #define PBRS_WIDE_MIN_LEVELS 4u  // scenes whose deepest BLAS has fewer wide levels keep the binary-walk kernels
 #endif
-#ifndef PBRS_PAIR_STACK_MAX
-#define PBRS_PAIR_STACK_MAX 24  // ... of the kernels that walk pair nodes: one entry per level at most
-#endif
 #define PBRS_WREF_LEAF 0x80000000u
 #define PBRS_WREF_NONE 0xffffffffu
 #define PBRS_WREF_INDEX 0x07ffffffu  // a leaf's index in DevScene::nodes (below 2^27: the node array is addressed with 32-bit byte offsets); a wide
@@ -64,15 +61,6 @@ struct WideRay {
     PD uint32_t ny() const { return (nb >> 8) & 0xffu; }
     PD uint32_t nz() const { return nb >> 16; }
 };
-
-// The reference's test needs the reciprocals (slab_rs): a wide walk asks for it a few times per ray (a mesh's root, the leaves
-// that come up) and does not keep them as walk state between node steps (forget_reciprocals) — a correctly rounded division is a
-// pure function of the direction, recomputing it gives the bits make_space had.
-PD RaySpace exact_space(const RaySpace& C) {
-    RaySpace E = C;
-    E.nr = mk3(-(1.0f / C.d.x), -(1.0f / C.d.y), -(1.0f / C.d.z));
-    return E;
-}
 
 struct WideTest {
     uint32_t pass;  // bit s: slot s passed the filter
@@ -141,106 +129,4 @@ PD uint32_t wide_push(const WideOrder& o, LaneStack stk, int& sp) {
     if (o.p[1] & o.p[0]) stk.put(sp + (int)(o.p[3] + o.p[2]), o.r[1]);
     sp += (int)(o.p[0] + o.p[1] + o.p[2] + o.p[3]) - 1;
     return o.p[0] ? o.r[0] : o.p[1] ? o.r[1] : o.p[2] ? o.r[2] : o.r[3];
-}
-
-// ---- pair nodes: the same argument taken ONE level at a time --------------------------------------------------------------------
-// A pair node holds the boxes of the two children of an inner node X of the reference's tree (left child in slot 0), tested
-// together with pn_slab_filter against the extent of that moment; the survivor the reference visits first (`ray.dir[axis] > 0`:
-// the left one) is taken next from a register, the other one pushed.  One dependent step per inner node that passes — the
-// binary walk takes one per box, pops of boxes that fail included — two filter tests in it instead of one exact test, 12 plane
-// coordinates and two links live instead of the 24 + 4 of a four-wide node (the closest-hit walk over those needs 117
-// registers: four waves per SIMD, where the binary walk has six).  Leaves come up unverified and get the reference's own test at
-// their turn, exactly as on the four-wide walk.
-struct pbrs_pnode {     // 64 bytes = half an L2 line
-    float lo[3][2];     // [axis][slot]: min planes   (bytes  0 .. 23)
-    float hi[3][2];     // [axis][slot]: max planes   (bytes 24 .. 47)
-    uint32_t child[2];  // PBRS_WREF_LEAF | index of the reference's leaf node in DevScene::nodes; else index of a pair node
-    uint32_t info;      // bits 0-1: split axis of X
-    uint32_t pad;
-};
-struct PairRay {
-    f3 r32;               // RN(1 / d) per component (-RaySpace::nr)
-    uint32_t nx, ny, nz;  // byte offset of the planes met first on that axis within the node: axis * 8 (+ 24 where the direction is not positive)
-    PD void set(const RaySpace& C) {
-        r32 = -C.nr;
-        nx = C.d.x > 0.0f ? 0u : 24u;
-        ny = C.d.y > 0.0f ? 8u : 32u;
-        nz = C.d.z > 0.0f ? 16u : 40u;
-    }
-    // `!(ray.dir[axis] > 0)`: the right child first (blas.rs:456-466)
-    PD bool right_first(uint32_t axis) const { return (axis == 0u ? nx : axis == 1u ? ny - 8u : nz - 16u) != 0u; }
-};
-struct PairTest {
-    uint32_t first, second;  // the children in the reference's visiting order
-    bool pf, ps;             // their boxes passed the filter
-};
-PD PairTest pair_test(const pbrs_wnode* nodes, uint32_t pi, const RaySpace& C, const PairRay& W, float t_max) {
-    const char* base = reinterpret_cast<const char*>(nodes);
-    const uint32_t at = pi * (uint32_t)sizeof(pbrs_pnode);
-    const float2 nx = *reinterpret_cast<const float2*>(base + (at + W.nx)), ny = *reinterpret_cast<const float2*>(base + (at + W.ny)),
-                 nz = *reinterpret_cast<const float2*>(base + (at + W.nz));
-    const float2 fx = *reinterpret_cast<const float2*>(base + (at + (24u - W.nx))), fy = *reinterpret_cast<const float2*>(base + (at + (40u - W.ny))),
-                 fz = *reinterpret_cast<const float2*>(base + (at + (56u - W.nz)));
-    const uint4 ch = *reinterpret_cast<const uint4*>(base + (at + 48u));
-    const bool p0 = pn_slab_filter(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, C.o.x, C.o.y, C.o.z, W.r32.x, W.r32.y, W.r32.z, t_max) != 0;
-    const bool p1 = pn_slab_filter(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, C.o.x, C.o.y, C.o.z, W.r32.x, W.r32.y, W.r32.z, t_max) != 0;
-    const bool swap = W.right_first(ch.z & 3u);
-    PairTest t;
-    t.first = swap ? ch.y : ch.x;
-    t.second = swap ? ch.x : ch.y;
-    t.pf = swap ? p1 : p0;
-    t.ps = swap ? p0 : p1;
-    return t;
-}
-
-// ---- compressed nodes: one 16-byte load per box --------------------------------------------------------------------------------
-// What bounds the traversal kernels is the CU's vector memory path as much as its vector ALUs: a load instruction whose 64 lanes
-// name 64 different lines costs the L1 one cycle per lane whatever its width (tools/microbench/gather_rates.hip), k_extend makes
-// 106 such accesses per ray on C4 (rocprofv3 TCP_TOTAL_CACHE_ACCESSES) — 0.89 per cycle and CU at full size, of a peak of 1 — and
-// a 32-byte node is two of them.  Since inner-node tests only prune (above), a walk may test a box that merely ENCLOSES the
-// node's: every BLAS node i gets a 16-byte record — its box on a 16-bit grid over its mesh, rounded outward, and its links —
-// fetched with ONE load and tested in grid coordinates with one multiply-add per plane.  A leaf whose record passes comes up
-// unverified, as on the wide walks, and the reference's own test reads the full node at the leaf's turn.
-//
-// Grid of a mesh (pbrs_upload_scene, build_cnodes): ONE step s for the three axes — the root box's longest side over 65532 —
-// and a base b one step below the root's min corner, so that every plane of the mesh lies between grid lines 1 and 65534.  A
-// record holds integers with  b + (q_lo + 1) s <= min plane  and  b + (q_hi - 1) s >= max plane  (real arithmetic; checked in
-// f64 at upload, where those sums are exact): the box on the grid, and ONE MORE STEP outward on every side.  That step pays for
-// every rounding on the way: for a ray (o, d) inside the guarded range, r = v_rcp_f32(d) (relative error <= 2^-22), CRay::set
-// computes A = RN(s r), B = RN(RN(b - o) r) per axis and the walk t' = RN(q A + B) — five roundings of relative size <= 2^-24
-// and r's, so  |t' - (b + q s - o) / d| <= 2^-21.5 (q |A| + |B|).  The reference's quotient RN(RN(p - o) / d) for the node's own
-// plane p is within 2^-23 (relative) of (p - o) / d.  A walk takes a ray onto the grid only while |B| <= 2^20 |A| on every axis
-// (its origin within 2^20 steps = 16 root boxes of the base: CRay::set's result; other rays go to the binary walk), where both
-// errors together stay below 2^-21 (2^16 + 2^20) |A| < 0.6 |A|, less than the extra step |A|.  Hence the quotient of the
-// record's plane lies on the outer side of the reference's quotient for the node's plane, on every axis, and with lo' =
-// max_axis min(t'), hi' = min_axis max(t') the reference's pass  max(lo_ref, 0) <= min(hi_ref, t_max)  implies
-// max(lo', 0) <= min(hi', t_max)  (min and max are monotone): cnode_filter never rejects a box the reference's test accepts.
-struct pbrs_cnode {
-    uint32_t x, y, z;  // q_lo | q_hi << 16 per axis
-    uint32_t link;     // bit 31: leaf; inner nodes: bits 29-30 the split axis, bits 0-28 the right child (the left one is i + 1)
-};
-#define PBRS_CNODE_LEAF 0x80000000u
-#define PBRS_CNODE_CHILD_MASK 0x1fffffffu
-#define PBRS_CNODE_RANGE 1048576.0f /* 2^20 grid steps */
-struct pbrs_cframe {  // the grid of an instance's mesh
-    float base[3], step;
-};
-struct CRay {
-    f3 A, B;
-    PD bool set(const RaySpace& C, const pbrs_cframe& f) {  // false: the ray's origin is too far from this grid
-        const f3 r = mk3(__builtin_amdgcn_rcpf(C.d.x), __builtin_amdgcn_rcpf(C.d.y), __builtin_amdgcn_rcpf(C.d.z));
-        A = mk3(f.step * r.x, f.step * r.y, f.step * r.z);
-        B = mk3((f.base[0] - C.o.x) * r.x, (f.base[1] - C.o.y) * r.y, (f.base[2] - C.o.z) * r.z);
-        return __builtin_fabsf(B.x) <= PBRS_CNODE_RANGE * __builtin_fabsf(A.x) && __builtin_fabsf(B.y) <= PBRS_CNODE_RANGE * __builtin_fabsf(A.y) &&
-               __builtin_fabsf(B.z) <= PBRS_CNODE_RANGE * __builtin_fabsf(A.z);
-    }
-};
-PD bool cnode_filter(const pbrs_cnode& n, const CRay& W, float t_max) {
-    // (explicit multiply-adds: contraction is off, and RN(q A) + B would be two roundings where the bound above counts one)
-    const float t0x = __builtin_fmaf((float)(n.x & 0xffffu), W.A.x, W.B.x), t1x = __builtin_fmaf((float)(n.x >> 16), W.A.x, W.B.x);
-    const float t0y = __builtin_fmaf((float)(n.y & 0xffffu), W.A.y, W.B.y), t1y = __builtin_fmaf((float)(n.y >> 16), W.A.y, W.B.y);
-    const float t0z = __builtin_fmaf((float)(n.z & 0xffffu), W.A.z, W.B.z), t1z = __builtin_fmaf((float)(n.z >> 16), W.A.z, W.B.z);
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
-    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
-    return __builtin_fmaxf(lo, 0.0f) <= __builtin_fminf(hi, t_max);
 }

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <utility>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -93,25 +94,29 @@ struct pbrs_ctx {
     bool split_lambert = true;     // PBRS_SPLIT_LAMBERT=0 in the environment: one general k_shade launch for all classes (A/B timing)
     uint32_t shade_spec = 0;       // PBRS_SHADE_*: what k_shade<PATH> may leave out for this scene
     bool long_walks = false;       // a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: the PBRS_FEAT_LONG_WALKS kernels
+    bool full_steps = false;       // ... whose further node steps are full ones (PBRS_FEAT_FULL_STEPS): what the walks read exceeds the last-level cache
+    uint64_t cache_bytes = 256ull << 20;  // the last-level cache the per-scene choices assume (MI355X: 256 MiB Infinity Cache); pbrs_set_cache_bytes
+    uint64_t walk_bytes = 0;       // bytes of the arrays the walks read (nodes, wide nodes, triangle vertices, instances)
+    bool lds_scene = false;        // ... and they fit next to a block's stack rows: the PBRS_FEAT_LDS_SCENE kernels (S.lds_*)
+    size_t lds_scene_bytes = 0;
     bool shadow_flat = false;      // k_shadow scans the TLAS leaves (up to PBRS_FLAT_TLAS_MAX_ANYHIT instances; k_extend: S.features)
     bool split_queue = true;       // k_extend splits the path integrator's queue of one-class scenes (shaded / terminal / dropped); PBRS_SPLIT_QUEUE=0 in developer builds
     // ... which pays where many paths are dropped (an open scene: C4 shades in 84 instead of 117 ms per frame) and costs where
     // none are (a closed box: the gathered records cost C2 4 %).  Decided once per uploaded scene, from the counts of the first
     // pass rendered with the path integrator: 0 = not yet, 1 = split, 2 = do not.  The image does not depend on it.
     int split_decision = 0;
+    // The counts travel to the host through a pinned buffer behind an event that later passes poll (hipEventQuery): no call of the
+    // render path waits for them, so pbrs_render_tile_device stays asynchronous (also on a caller's stream, pbrs_set_stream).
+    unsigned long long* split_host = nullptr;  // pinned: (paths kept, paths in all) of the probed pass
+    hipEvent_t split_ev = nullptr;
+    bool split_probe_in_flight = false;
     bool wide_extend = false, wide_shadow = false;  // the stage runs the walks over four-wide nodes (device/wide.h), the binary walks after it for what they refuse
-    bool pair_extend = false, pair_shadow = false;  // ... over pair nodes (device/wide.h) instead; wide_* is set as well
-    const pbrs_wnode* pnodes = nullptr;             // the pair nodes (kernels read them through DevScene::wnodes)
-    const uint32_t* proot = nullptr;                // per instance: the pair node of its mesh's root
-    uint32_t pair_cap = 0;                          // stack rows of the pair-node walks
-    bool grid_extend = false, grid_shadow = false;    // the stage's binary walk tests a mesh's boxes on the compressed records (traverse.h, GRID walks)
-    bool cnode_extend = false, cnode_shadow = false;  // ... over the binary tree's compressed records (device/wide.h); wide_* is set as well
-    uint32_t cnode_cap_x = 0, cnode_cap_s = 0;        // stack rows of those walks (k_extend, k_shadow): one entry per level, capped so that six blocks fit a CU
     uint32_t* slow = nullptr;      // 2 * cap_slots: queue positions a wide-walk kernel handed to the binary-walk kernel
     bool has_vis_records = false;  // every material names its pbrs_material::vis_bxdf record (normal_visualizer)
     bool sort_classes = true;      // PBRS_SORT_CLASSES=0 in the environment turns the class sort off (A/B timing)
     bool split_fourier = true;     // PBRS_SPLIT_FOURIER=0 in developer builds: one launch of the Fourier variants over every class, as in round 2
     uint64_t pending_closest = 0;
+    pbrs_intersect_info last_intersect{};  // which walks the last pbrs_intersect_rays went through
 };
 
 namespace {
@@ -223,19 +228,7 @@ int ensure_work(pbrs_ctx* c, size_t n_slots, size_t n_pixels) {
 
 // wide-walk kernels: DevScene::wide_cap stack rows, and for closest hit one row per scanned TLAS leaf (entry distances)
 size_t lds_bytes_wide(const pbrs_ctx* c, bool closest) {
-    const uint32_t cap = (closest ? c->cnode_extend : c->cnode_shadow) ? (closest ? c->cnode_cap_x : c->cnode_cap_s) : (closest ? c->pair_extend : c->pair_shadow) ? c->pair_cap : c->S.wide_cap;
-    return (size_t)(cap + (closest ? c->S.n_flat : 0u)) * kBlock * sizeof(uint32_t);
-}
-// the scene as a kernel that walks pair nodes sees it (kernels.h: the pair nodes travel in the wide nodes' fields)
-DevScene cnode_view(const pbrs_ctx* c, DevScene S, bool closest) {
-    S.wide_cap = closest ? c->cnode_cap_x : c->cnode_cap_s;
-    return S;
-}
-DevScene pair_view(const pbrs_ctx* c, DevScene S) {
-    S.wnodes = c->pnodes;
-    S.wide_cap = c->pair_cap;
-    S.wroot = c->proot;
-    return S;
+    return (size_t)(c->S.wide_cap + (closest ? c->S.n_flat : 0u)) * kBlock * sizeof(uint32_t);
 }
 size_t lds_bytes(const pbrs_ctx* c) {
     size_t b = (size_t)(c->stack_depth) * kBlock * sizeof(uint32_t);
@@ -309,80 +302,6 @@ uint32_t build_wide(const std::vector<pbrs_node>& nodes, uint32_t x, std::vector
     w.child[0] |= (info & 15u) << PBRS_WREF_AXIS_SHIFT;  // slots 0 and 2 are always in use
     w.child[2] |= ((info >> 4) & 3u) << PBRS_WREF_AXIS_SHIFT;
     out[me] = w;
-    return me;
-}
-
-// Compressed records (device/wide.h) of the BLAS below `root` on the grid of that BLAS: one step for the three axes, the base one
-// step below the root's min corner, every plane rounded to the grid line on its outer side and moved one more step outward.  All
-// comparisons are made in f64, where b + q s is exact (24 + 17 + 24 bits).  False: the root box does not admit such a grid
-// (non-finite or absurdly large coordinates: the scene then keeps the walks over full nodes).
-bool build_cnodes(const std::vector<pbrs_node>& nodes, uint32_t root, std::vector<pbrs_cnode>& out, pbrs_cframe& frame) {
-    const pbrs_node& r = nodes[root];
-    double ext = 0.0;
-    for (int a = 0; a < 3; ++a) ext = std::max(ext, (double)r.max[a] - (double)r.min[a]);
-    if (!(ext >= 0.0) || !std::isfinite(ext)) return false;
-    float s = (float)(ext / 65532.0);
-    if (!(s > 0.0f)) s = 1e-30f;  // a mesh of one point
-    for (int tries = 0;; ++tries) {
-        bool ok = true;
-        for (int a = 0; a < 3; ++a) {
-            float b = (float)((double)r.min[a] - (double)s);
-            while ((double)b + (double)s > (double)r.min[a]) b = std::nextafter(b, -INFINITY);  // grid line 1 at or below the min plane
-            frame.base[a] = b;
-            ok = ok && (double)b + 65534.0 * (double)s >= (double)r.max[a];                    // grid line 65534 at or above the max plane
-        }
-        if (ok) break;
-        if (tries > 64) return false;
-        s = std::nextafter(s, INFINITY);
-    }
-    frame.step = s;
-    std::vector<uint32_t> todo{root};
-    while (!todo.empty()) {
-        const uint32_t i = todo.back();
-        todo.pop_back();
-        const pbrs_node& n = nodes[i];
-        uint32_t q[3];
-        for (int a = 0; a < 3; ++a) {
-            const double b = frame.base[a], sd = s;
-            long lo = (long)std::floor(((double)n.min[a] - b) / sd), hi = (long)std::ceil(((double)n.max[a] - b) / sd);
-            lo = std::min(std::max(lo, 1l), 65534l);
-            hi = std::min(std::max(hi, 1l), 65534l);
-            while (lo > 1 && b + (double)lo * sd > (double)n.min[a]) --lo;
-            while (hi < 65534 && b + (double)hi * sd < (double)n.max[a]) ++hi;
-            if (b + (double)lo * sd > (double)n.min[a] || b + (double)hi * sd < (double)n.max[a]) return false;  // a node outside its root's box
-            q[a] = (uint32_t)(lo - 1) | (uint32_t)(hi + 1) << 16;
-        }
-        pbrs_cnode c{q[0], q[1], q[2], 0u};
-        if (n.b & PBRS_LEAF_FLAG) {
-            c.link = PBRS_CNODE_LEAF;
-        } else {
-            c.link = (n.b & 3u) << 29 | (n.a & PBRS_CNODE_CHILD_MASK);
-            todo.push_back(i + 1u);
-            todo.push_back(n.a);
-        }
-        out[i] = c;
-    }
-    return true;
-}
-
-// Pair nodes over the binary subtree of inner node x (device/wide.h): the boxes of x's two children, the left one in slot 0.
-// Returns the index of x's pair node in `out`; `levels`: pair nodes on the longest way down.
-uint32_t build_pair(const std::vector<pbrs_node>& nodes, uint32_t x, std::vector<pbrs_pnode>& out, uint32_t level, uint32_t& levels) {
-    const uint32_t me = (uint32_t)out.size();
-    out.push_back(pbrs_pnode{});
-    levels = std::max(levels, level + 1u);
-    pbrs_pnode p{};
-    p.info = nodes[x].b & 3u;
-    const uint32_t child[2] = {x + 1u, nodes[x].a};
-    for (uint32_t s = 0; s < 2; ++s) {
-        const pbrs_node& n = nodes[child[s]];
-        for (int a = 0; a < 3; ++a) {
-            p.lo[a][s] = n.min[a];
-            p.hi[a][s] = n.max[a];
-        }
-        p.child[s] = (n.b & PBRS_LEAF_FLAG) ? (PBRS_WREF_LEAF | child[s]) : build_pair(nodes, child[s], out, level + 1u, levels);
-    }
-    out[me] = p;
     return me;
 }
 
@@ -461,183 +380,110 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
     return (uint32_t)k;
 }
 
-// The traversal kernels are instantiated per scene-feature set (device/shapes.h PBRS_FEAT_*); the instrumented variant
-// exists for the full set only.  k_shadow never evaluates shading frames, so only PBRS_FEAT_ANALYTIC selects it.
-// `wide`: the walks over four-wide nodes (scenes with a scanned TLAS); `indirect` / `slow_*`: see kernels.h.
-void launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* heads,
-                   const uint32_t* indirect, uint32_t* slow_list, uint32_t* slow_count, uint32_t split) {
+// The traversal kernels are instantiated per scene-feature set (device/shapes.h PBRS_FEAT_*): one table entry per valid combination,
+// filled at compile time; the instrumented variant exists for the full set only.  k_shadow never evaluates shading frames, so
+// PBRS_FEAT_SHADING_CHECK does not select it.  `wide`: the walks over four-wide nodes (scenes with a scanned TLAS); `indirect` /
+// `slow_*`: see kernels.h.
+typedef void (*extend_fn_t)(DevScene, PathState, uint32_t, const uint32_t*, uint32_t, uint32_t*, GlobalCounters*, const uint32_t*, uint32_t*, uint32_t*, uint32_t);
+typedef void (*shadow_fn_t)(DevScene, PathState, const uint32_t*, uint32_t*, GlobalCounters*, const uint32_t*, uint32_t*, uint32_t*);
+constexpr uint32_t kFeatCombos = 128u;  // PBRS_FEAT_* bits 0 .. 6
+constexpr bool extend_feat_ok(uint32_t f) {
+    if ((f & PBRS_FEAT_FULL_STEPS) && !(f & PBRS_FEAT_LONG_WALKS)) return false;  // further node steps exist in the long-walk kernels only
+    if ((f & PBRS_FEAT_LDS_SCENE) && (f & (PBRS_FEAT_WIDE | PBRS_FEAT_FULL_STEPS))) return false;  // a scene of a few KB
+    if (f & PBRS_FEAT_WIDE) {
+#ifdef PBRS_DEV_OVERRIDES  // the four-wide closest-hit walk (device/experimental/closest_wide.h)
+        return (f & PBRS_FEAT_FLAT_TLAS) && !(f & PBRS_FEAT_FULL_STEPS);
+#else
+        return false;
+#endif
+    }
+    return true;
+}
+constexpr bool shadow_feat_ok(uint32_t f) {
+    if (f & PBRS_FEAT_SHADING_CHECK) return false;
+    if ((f & PBRS_FEAT_FULL_STEPS) && !(f & PBRS_FEAT_LONG_WALKS)) return false;
+    if ((f & PBRS_FEAT_LDS_SCENE) && (f & (PBRS_FEAT_WIDE | PBRS_FEAT_FULL_STEPS))) return false;
+    if ((f & PBRS_FEAT_WIDE) && !(f & PBRS_FEAT_FLAT_TLAS)) return false;
+    return true;
+}
+template <uint32_t F>
+constexpr extend_fn_t extend_fn_of() {
+    if constexpr (extend_feat_ok(F)) return &k_extend<false, F>;
+    else return nullptr;
+}
+template <uint32_t F>
+constexpr shadow_fn_t shadow_fn_of() {
+    if constexpr (shadow_feat_ok(F)) return &k_shadow<false, F>;
+    else return nullptr;
+}
+template <uint32_t... F>
+const extend_fn_t* extend_table(std::integer_sequence<uint32_t, F...>) {
+    static const extend_fn_t t[sizeof...(F)] = {extend_fn_of<F>()...};
+    return t;
+}
+template <uint32_t... F>
+const shadow_fn_t* shadow_table(std::integer_sequence<uint32_t, F...>) {
+    static const shadow_fn_t t[sizeof...(F)] = {shadow_fn_of<F>()...};
+    return t;
+}
+const extend_fn_t* extend_fns() { return extend_table(std::make_integer_sequence<uint32_t, kFeatCombos>{}); }
+const shadow_fn_t* shadow_fns() { return shadow_table(std::make_integer_sequence<uint32_t, kFeatCombos>{}); }
+
+int launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* heads,
+                  const uint32_t* indirect, uint32_t* slow_list, uint32_t* slow_count, uint32_t split) {
     // k_extend scans the TLAS leaves only up to PBRS_FLAT_TLAS_MAX instances (S.features); the leaf copies may exist for
     // k_shadow alone, and the instrumented variant, which carries every feature, must then walk the tree like the timed one
     DevScene S = c->S;
     if (!(S.features & PBRS_FEAT_FLAT_TLAS)) S.n_flat = 0u;
-#define PBRS_LAUNCH_EXTEND(ST, F) \
-    hipLaunchKernelGGL((k_extend<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt, indirect, slow_list, slow_count, \
-                       split)
     if (stats) {
-        PBRS_LAUNCH_EXTEND(true, PBRS_FEAT_ALL);
-        return;
+        hipLaunchKernelGGL((k_extend<true, PBRS_FEAT_ALL>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt, indirect, slow_list,
+                           slow_count, split);
+        c->pending.kernel_features_extend = PBRS_FEAT_ALL | 0x80000000u;
+        return PBRS_OK;
     }
-    const uint32_t feat = (c->S.features & PBRS_FEAT_ALL) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u);
-#ifdef PBRS_DEV_OVERRIDES  // the walks over compressed records, pair nodes and (closest hit) four-wide nodes lose against the binary walk
-                           // at six waves per SIMD: developer builds only
-    if (wide && c->cnode_extend) {  // PBRS_FEAT_FLAT_TLAS is set (pbrs_upload_scene)
-        S = cnode_view(c, S, true);
-#define W PBRS_FEAT_CNODE | PBRS_FEAT_FLAT_TLAS
-        switch (feat & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_LONG_WALKS)) {
-            case 0u: PBRS_LAUNCH_EXTEND(false, W); break;
-            case 1u: PBRS_LAUNCH_EXTEND(false, W | 1u); break;
-            case 2u: PBRS_LAUNCH_EXTEND(false, W | 2u); break;
-            case 3u: PBRS_LAUNCH_EXTEND(false, W | 3u); break;
-            case 8u: PBRS_LAUNCH_EXTEND(false, W | 8u); break;
-            case 9u: PBRS_LAUNCH_EXTEND(false, W | 9u); break;
-            case 10u: PBRS_LAUNCH_EXTEND(false, W | 10u); break;
-            default: PBRS_LAUNCH_EXTEND(false, W | 11u); break;
-        }
-#undef W
-        return;
+    uint32_t feat = (c->S.features & PBRS_FEAT_ALL) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u) | ((c->long_walks && c->full_steps) ? PBRS_FEAT_FULL_STEPS : 0u);
+    if (wide) feat = (feat & ~PBRS_FEAT_FULL_STEPS) | PBRS_FEAT_WIDE;  // (developer builds; PBRS_FEAT_FLAT_TLAS is set: pbrs_upload_scene)
+    if (c->lds_scene && !wide) {
+        feat |= PBRS_FEAT_LDS_SCENE;
+        lds += c->lds_scene_bytes;
     }
-    if (wide && c->pair_extend) {  // PBRS_FEAT_FLAT_TLAS is set (pbrs_upload_scene)
-        S = pair_view(c, S);
-#define W PBRS_FEAT_PAIR | PBRS_FEAT_FLAT_TLAS
-        switch (feat & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_LONG_WALKS)) {
-            case 0u: PBRS_LAUNCH_EXTEND(false, W); break;
-            case 1u: PBRS_LAUNCH_EXTEND(false, W | 1u); break;
-            case 2u: PBRS_LAUNCH_EXTEND(false, W | 2u); break;
-            case 3u: PBRS_LAUNCH_EXTEND(false, W | 3u); break;
-            case 8u: PBRS_LAUNCH_EXTEND(false, W | 8u); break;
-            case 9u: PBRS_LAUNCH_EXTEND(false, W | 9u); break;
-            case 10u: PBRS_LAUNCH_EXTEND(false, W | 10u); break;
-            default: PBRS_LAUNCH_EXTEND(false, W | 11u); break;
-        }
-#undef W
-        return;
-    }
-    if (wide) {  // PBRS_FEAT_FLAT_TLAS is set (pbrs_upload_scene)
-#define W PBRS_FEAT_WIDE | PBRS_FEAT_FLAT_TLAS
-        switch (feat & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_LONG_WALKS)) {
-            case 0u: PBRS_LAUNCH_EXTEND(false, W); break;
-            case 1u: PBRS_LAUNCH_EXTEND(false, W | 1u); break;
-            case 2u: PBRS_LAUNCH_EXTEND(false, W | 2u); break;
-            case 3u: PBRS_LAUNCH_EXTEND(false, W | 3u); break;
-            case 8u: PBRS_LAUNCH_EXTEND(false, W | 8u); break;
-            case 9u: PBRS_LAUNCH_EXTEND(false, W | 9u); break;
-            case 10u: PBRS_LAUNCH_EXTEND(false, W | 10u); break;
-            default: PBRS_LAUNCH_EXTEND(false, W | 11u); break;
-        }
-#undef W
-        return;
-    }
-#else
-    (void)wide;
-#endif
-#ifdef PBRS_DEV_OVERRIDES  // (measured: with 37 % fewer L1 accesses per ray and the same six waves per SIMD, 4 % slower on C4, 30 % on C2 / C3: DESIGN.md)
-    if (c->grid_extend && (feat & PBRS_FEAT_FLAT_TLAS) && S.n_flat != 0u) {
-#define G PBRS_FEAT_GRID | PBRS_FEAT_FLAT_TLAS
-        switch (feat & (PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_LONG_WALKS)) {
-            case 0u: PBRS_LAUNCH_EXTEND(false, G); break;
-            case 1u: PBRS_LAUNCH_EXTEND(false, G | 1u); break;
-            case 2u: PBRS_LAUNCH_EXTEND(false, G | 2u); break;
-            case 3u: PBRS_LAUNCH_EXTEND(false, G | 3u); break;
-            case 8u: PBRS_LAUNCH_EXTEND(false, G | 8u); break;
-            case 9u: PBRS_LAUNCH_EXTEND(false, G | 9u); break;
-            case 10u: PBRS_LAUNCH_EXTEND(false, G | 10u); break;
-            default: PBRS_LAUNCH_EXTEND(false, G | 11u); break;
-        }
-#undef G
-        return;
-    }
-#endif
-    switch (feat) {
-        case 0u: PBRS_LAUNCH_EXTEND(false, 0u); break;
-        case 1u: PBRS_LAUNCH_EXTEND(false, 1u); break;
-        case 2u: PBRS_LAUNCH_EXTEND(false, 2u); break;
-        case 3u: PBRS_LAUNCH_EXTEND(false, 3u); break;
-        case 4u: PBRS_LAUNCH_EXTEND(false, 4u); break;
-        case 5u: PBRS_LAUNCH_EXTEND(false, 5u); break;
-        case 6u: PBRS_LAUNCH_EXTEND(false, 6u); break;
-        case 7u: PBRS_LAUNCH_EXTEND(false, 7u); break;
-        case 8u: PBRS_LAUNCH_EXTEND(false, 8u); break;
-        case 9u: PBRS_LAUNCH_EXTEND(false, 9u); break;
-        case 10u: PBRS_LAUNCH_EXTEND(false, 10u); break;
-        case 11u: PBRS_LAUNCH_EXTEND(false, 11u); break;
-        case 12u: PBRS_LAUNCH_EXTEND(false, 12u); break;
-        case 13u: PBRS_LAUNCH_EXTEND(false, 13u); break;
-        case 14u: PBRS_LAUNCH_EXTEND(false, 14u); break;
-        default: PBRS_LAUNCH_EXTEND(false, 15u); break;
-    }
-#undef PBRS_LAUNCH_EXTEND
+    const extend_fn_t fn = extend_fns()[feat];
+    if (!fn) return fail(c, PBRS_E_DEVICE, "no k_extend instantiation for this scene's feature set");
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt, indirect, slow_list, slow_count, split);
+    if (!indirect) c->pending.kernel_features_extend = feat;  // (a launch over a slow list is the stage's second kernel)
+    return PBRS_OK;
 }
-void launch_shadow(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds, const uint32_t* count, uint32_t* heads, const uint32_t* indirect,
-                   uint32_t* slow_list, uint32_t* slow_count) {
-    DevScene S = c->S;
-#define PBRS_LAUNCH_SHADOW(ST, F) \
-    hipLaunchKernelGGL((k_shadow<ST, F>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, count, heads, c->gcnt + 1, indirect, slow_list, slow_count)
-    // k_shadow never evaluates shading frames: PBRS_FEAT_SHADING_CHECK does not select it
+int launch_shadow(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds, const uint32_t* count, uint32_t* heads, const uint32_t* indirect,
+                  uint32_t* slow_list, uint32_t* slow_count) {
     if (stats) {
-        PBRS_LAUNCH_SHADOW(true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS);
+        hipLaunchKernelGGL((k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, count, heads, c->gcnt + 1,
+                           indirect, slow_list, slow_count);
+        c->pending.kernel_features_shadow = PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS | 0x80000000u;
+        return PBRS_OK;
+    }
+    uint32_t feat = (c->S.features & PBRS_FEAT_ANALYTIC) | (c->shadow_flat ? PBRS_FEAT_FLAT_TLAS : 0u) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u) |
+                    ((c->long_walks && c->full_steps) ? PBRS_FEAT_FULL_STEPS : 0u);
+    if (wide) feat |= PBRS_FEAT_WIDE;  // (PBRS_FEAT_FLAT_TLAS is set: pbrs_upload_scene)
+    if (c->lds_scene && !wide) {
+        feat |= PBRS_FEAT_LDS_SCENE;
+        lds += c->lds_scene_bytes;
+    }
+    const shadow_fn_t fn = shadow_fns()[feat];
+    if (!fn) return fail(c, PBRS_E_DEVICE, "no k_shadow instantiation for this scene's feature set");
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, c->stream, c->S, c->st, count, heads, c->gcnt + 1, indirect, slow_list, slow_count);
+    if (!indirect) c->pending.kernel_features_shadow = feat;
+    return PBRS_OK;
+}
+
+// The split probe of an earlier pass (run_pass), if its counts have arrived: keep the queue split where it keeps at most
+// PBRS_SPLIT_KEEP_PERCENT of a pass's rays for k_shade.  Never waits.
+void poll_split_probe(pbrs_ctx* c) {
+    if (!c->split_probe_in_flight || hipEventQuery(c->split_ev) != hipSuccess) {
+        (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
         return;
     }
-#ifdef PBRS_DEV_OVERRIDES
-    if (wide && c->cnode_shadow) {
-        S = cnode_view(c, S, false);
-#define W PBRS_FEAT_CNODE | PBRS_FEAT_FLAT_TLAS
-        switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
-            case 0u: PBRS_LAUNCH_SHADOW(false, W); break;
-            case 1u: PBRS_LAUNCH_SHADOW(false, W | 1u); break;
-            case 8u: PBRS_LAUNCH_SHADOW(false, W | 8u); break;
-            default: PBRS_LAUNCH_SHADOW(false, W | 9u); break;
-        }
-#undef W
-        return;
-    }
-    if (wide && c->pair_shadow) {
-        S = pair_view(c, S);
-#define W PBRS_FEAT_PAIR | PBRS_FEAT_FLAT_TLAS
-        switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
-            case 0u: PBRS_LAUNCH_SHADOW(false, W); break;
-            case 1u: PBRS_LAUNCH_SHADOW(false, W | 1u); break;
-            case 8u: PBRS_LAUNCH_SHADOW(false, W | 8u); break;
-            default: PBRS_LAUNCH_SHADOW(false, W | 9u); break;
-        }
-#undef W
-        return;
-    }
-#endif
-    if (wide) {
-#define W PBRS_FEAT_WIDE | PBRS_FEAT_FLAT_TLAS
-        switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
-            case 0u: PBRS_LAUNCH_SHADOW(false, W); break;
-            case 1u: PBRS_LAUNCH_SHADOW(false, W | 1u); break;
-            case 8u: PBRS_LAUNCH_SHADOW(false, W | 8u); break;
-            default: PBRS_LAUNCH_SHADOW(false, W | 9u); break;
-        }
-#undef W
-        return;
-    }
-#ifdef PBRS_DEV_OVERRIDES
-    if (c->grid_shadow && c->shadow_flat && S.n_flat != 0u) {
-#define G PBRS_FEAT_GRID | PBRS_FEAT_FLAT_TLAS
-        switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
-            case 0u: PBRS_LAUNCH_SHADOW(false, G); break;
-            case 1u: PBRS_LAUNCH_SHADOW(false, G | 1u); break;
-            case 8u: PBRS_LAUNCH_SHADOW(false, G | 8u); break;
-            default: PBRS_LAUNCH_SHADOW(false, G | 9u); break;
-        }
-#undef G
-        return;
-    }
-#endif
-    switch ((c->S.features & PBRS_FEAT_ANALYTIC) | (c->shadow_flat ? PBRS_FEAT_FLAT_TLAS : 0u) | (c->long_walks ? PBRS_FEAT_LONG_WALKS : 0u)) {
-        case 0u: PBRS_LAUNCH_SHADOW(false, 0u); break;
-        case PBRS_FEAT_ANALYTIC: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC); break;
-        case PBRS_FEAT_FLAT_TLAS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_FLAT_TLAS); break;
-        case PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS); break;
-        case PBRS_FEAT_LONG_WALKS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_LONG_WALKS); break;
-        case PBRS_FEAT_LONG_WALKS | PBRS_FEAT_ANALYTIC: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_LONG_WALKS | PBRS_FEAT_ANALYTIC); break;
-        case PBRS_FEAT_LONG_WALKS | PBRS_FEAT_FLAT_TLAS: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_LONG_WALKS | PBRS_FEAT_FLAT_TLAS); break;
-        default: PBRS_LAUNCH_SHADOW(false, PBRS_FEAT_LONG_WALKS | PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS); break;
-    }
-#undef PBRS_LAUNCH_SHADOW
+    c->split_probe_in_flight = false;
+    c->split_decision = (c->split_host[0] * 100ull <= c->split_host[1] * PBRS_SPLIT_KEEP_PERCENT) ? 1 : 2;
 }
 
 // One pass: kc sample indices starting at `first` for every pixel of the tile.
@@ -669,10 +515,13 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, c->st, rc);
     tm.end();
     const size_t lds = lds_bytes(c);
+    poll_split_probe(c);
     // the direct-lighting integrator is at most two rays deep whatever `depth` says (directlighting.rs:15-17, :36, :49)
     const uint32_t n_bounces = rc.integrator == PBRS_INTEGRATOR_DIRECT      ? (rc.max_depth ? 2u : 0u)
                                : rc.integrator >= PBRS_INTEGRATOR_MATERIALS ? 1u  // the visualisers: one cast, no lights
                                                                             : rc.max_depth;
+    // this pass counts what k_extend's queue split keeps (the first path-integrator pass of an uploaded one-class scene)
+    const bool probe_split = c->split_decision == 0 && !c->split_probe_in_flight && rc.integrator == PBRS_INTEGRATOR_PATH && c->S.n_classes <= 1u && c->split_queue && n_bounces > 0;
     for (uint32_t b = 0; b < n_bounces; ++b) {
         // bounce b reads the path records of set b & 1 (k_raygen wrote set 0) and k_shade writes set (b + 1) & 1; the
         // queue length of bounce 0 is the pass size, later ones are counted on the device
@@ -681,9 +530,10 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         // the path integrator on a scene with one shading class (no class sort): k_extend splits its queue into the hits k_shade
         // shades, the paths that only end (emitter hits, misses that see the environment) and the misses nothing happens to
         const uint32_t qsplit = (rc.integrator == PBRS_INTEGRATOR_PATH && c->S.n_classes <= 1u && c->split_queue && c->split_decision != 2) ? (1u | (b == 0 ? 2u : 0u)) : 0u;
-        launch_extend(c, stats, wide_x, pgrid, wide_x ? lds_wx : lds, b & 1u, cnt_in, N, xhead + b * kHeadWords, nullptr, c->slow, slowx + b, qsplit);
-        if (wide_x)  // what the wide walks refused (rays outside the guarded range of the division-free box test, overlong stacks)
-            launch_extend(c, false, false, pgrid < kSlowGrid ? pgrid : kSlowGrid, lds, b & 1u, slowx + b, 0u, xhead2 + b * kHeadWords, c->slow, nullptr, nullptr, qsplit);
+        int lrc = launch_extend(c, stats, wide_x, pgrid, wide_x ? lds_wx : lds, b & 1u, cnt_in, N, xhead + b * kHeadWords, nullptr, c->slow, slowx + b, qsplit);
+        if (!lrc && wide_x)  // what the wide walks refused (rays outside the guarded range of the division-free box test, overlong stacks)
+            lrc = launch_extend(c, false, false, pgrid < kSlowGrid ? pgrid : kSlowGrid, lds, b & 1u, slowx + b, 0u, xhead2 + b * kHeadWords, c->slow, nullptr, nullptr, qsplit);
+        if (lrc) return lrc;
         tm.end();
         if (tm.begin(2)) return fail(c, PBRS_E_DEVICE, "event record failed");
         // several shading classes (and an integrator that shades): order the queue by class first; counted as shade time
@@ -699,7 +549,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
             if (qsplit) hipLaunchKernelGGL(k_class_count<2u>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
             else hipLaunchKernelGGL(k_class_count<PBRS_MAX_CLASSES>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
             hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64 * PBRS_MAX_CLASSES), 0, c->stream, c->st, cnt_in, N, qsplit ? 1u : fsplit ? c->fourier_class : c->lambert_class,
-                               (qsplit && c->split_decision == 0) ? c->bounce_acc + 2 * PBRS_STATS_MAX_BOUNCES : nullptr);
+                               (qsplit && probe_split) ? c->bounce_acc + 2 * PBRS_STATS_MAX_BOUNCES : nullptr);
             if (qsplit) hipLaunchKernelGGL(k_class_scatter<2u>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
             else hipLaunchKernelGGL(k_class_scatter<PBRS_MAX_CLASSES>, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
         } else if (sorted) {
@@ -768,21 +618,22 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
         }
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
-        launch_shadow(c, stats, wide_s, pgrid, wide_s ? lds_ws : lds, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords, nullptr, c->slow, slows + b);
-        if (wide_s)
-            launch_shadow(c, false, false, pgrid < kSlowGrid ? pgrid : kSlowGrid, lds, slows + b, shead2 + b * kHeadWords, c->slow, nullptr, nullptr);
+        lrc = launch_shadow(c, stats, wide_s, pgrid, wide_s ? lds_ws : lds, reinterpret_cast<const uint32_t*>(ns + b), shead + b * kHeadWords, nullptr, c->slow, slows + b);
+        if (!lrc && wide_s)
+            lrc = launch_shadow(c, false, false, pgrid < kSlowGrid ? pgrid : kSlowGrid, lds, slows + b, shead2 + b * kHeadWords, c->slow, nullptr, nullptr);
+        if (lrc) return lrc;
         hipLaunchKernelGGL(k_nee_resolve, dim3(sgrid), dim3(kBlock), 0, c->stream, c->st, neeq, reinterpret_cast<const uint32_t*>(ns + b));
         tm.end();
     }
-    if (c->split_decision == 0 && rc.integrator == PBRS_INTEGRATOR_PATH && c->S.n_classes <= 1u && c->split_queue && n_bounces > 0) {
-        // the first pass of this scene through the path integrator: how much of its queues did the split keep for k_shade?
-        // (one synchronisation per uploaded scene; the image does not depend on the answer)
-        unsigned long long kept_all[2] = {0, 0};
+    if (probe_split) {
+        // the first pass of this scene through the path integrator: how much of its queues did the split keep for k_shade?  The
+        // counts are copied out behind an event; a later pass that finds the event complete takes the decision (poll_split_probe).
+        // No synchronisation; the image does not depend on the answer.
         unsigned long long* acc = c->bounce_acc + 2 * PBRS_STATS_MAX_BOUNCES;
-        HIPCHK(c, hipMemcpyAsync(kept_all, acc, sizeof kept_all, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemsetAsync(acc, 0, sizeof kept_all, c->stream));
-        c->split_decision = (kept_all[0] * 100ull <= kept_all[1] * PBRS_SPLIT_KEEP_PERCENT) ? 1 : 2;
+        HIPCHK(c, hipMemcpyAsync(c->split_host, acc, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->split_ev, c->stream));
+        HIPCHK(c, hipMemsetAsync(acc, 0, 2 * sizeof(unsigned long long), c->stream));
+        c->split_probe_in_flight = true;
     }
     if (stats)  // queue sizes of this pass, bounce by bounce (the counters are cleared at the start of every pass)
         hipLaunchKernelGGL(k_sum_bounce_counts, dim3(1), dim3(64), 0, c->stream, act, ns, N, n_bounces, c->bounce_acc);
@@ -881,35 +732,19 @@ int configure_kernels(pbrs_ctx* c) {
     std::lock_guard<std::mutex> lock(g_kernel_cfg_mutex);
     if (c->device < 64 && g_kernel_cfg_done[c->device]) return PBRS_OK;
     const int cap = (int)(kLdsBytesPerCU / 2);
-#define PBRS_K(expr) reinterpret_cast<const void*>(&expr)
-    const void* traversal_kernels[] = {
-        PBRS_K((k_extend<false, 0u>)),  PBRS_K((k_extend<false, 1u>)),  PBRS_K((k_extend<false, 2u>)),  PBRS_K((k_extend<false, 3u>)),
-        PBRS_K((k_extend<false, 4u>)),  PBRS_K((k_extend<false, 5u>)),  PBRS_K((k_extend<false, 6u>)),  PBRS_K((k_extend<false, 7u>)),
-        PBRS_K((k_extend<false, 8u>)),  PBRS_K((k_extend<false, 9u>)),  PBRS_K((k_extend<false, 10u>)), PBRS_K((k_extend<false, 11u>)),
-        PBRS_K((k_extend<false, 12u>)), PBRS_K((k_extend<false, 13u>)), PBRS_K((k_extend<false, 14u>)), PBRS_K((k_extend<false, 15u>)),
-        PBRS_K((k_extend<true, PBRS_FEAT_ALL>)),
-        PBRS_K((k_shadow<false, 0u>)), PBRS_K((k_shadow<false, 1u>)), PBRS_K((k_shadow<false, 4u>)), PBRS_K((k_shadow<false, 5u>)),
-        PBRS_K((k_shadow<false, 8u>)), PBRS_K((k_shadow<false, 9u>)), PBRS_K((k_shadow<false, 12u>)), PBRS_K((k_shadow<false, 13u>)),
-        PBRS_K((k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>)), PBRS_K(k_intersect_rays<false>), PBRS_K(k_intersect_rays<true>),
+    std::vector<const void*> traversal_kernels = {reinterpret_cast<const void*>(&k_extend<true, PBRS_FEAT_ALL>),
+                                                  reinterpret_cast<const void*>(&k_shadow<true, PBRS_FEAT_ANALYTIC | PBRS_FEAT_FLAT_TLAS>),
+                                                  reinterpret_cast<const void*>(&k_intersect_rays<false, false>),
+                                                  reinterpret_cast<const void*>(&k_intersect_rays<false, true>),
 #ifdef PBRS_DEV_OVERRIDES
-        PBRS_K((k_extend<false, 132u>)), PBRS_K((k_extend<false, 133u>)), PBRS_K((k_extend<false, 134u>)), PBRS_K((k_extend<false, 135u>)),
-        PBRS_K((k_extend<false, 140u>)), PBRS_K((k_extend<false, 141u>)), PBRS_K((k_extend<false, 142u>)), PBRS_K((k_extend<false, 143u>)),
-        PBRS_K((k_shadow<false, 132u>)), PBRS_K((k_shadow<false, 133u>)), PBRS_K((k_shadow<false, 140u>)), PBRS_K((k_shadow<false, 141u>)),
+                                                  reinterpret_cast<const void*>(&k_intersect_rays<true, false>),
+                                                  reinterpret_cast<const void*>(&k_intersect_rays<true, true>),
 #endif
-#ifdef PBRS_DEV_OVERRIDES
-        PBRS_K((k_extend<false, 20u>)), PBRS_K((k_extend<false, 21u>)), PBRS_K((k_extend<false, 22u>)), PBRS_K((k_extend<false, 23u>)),
-        PBRS_K((k_extend<false, 28u>)), PBRS_K((k_extend<false, 29u>)), PBRS_K((k_extend<false, 30u>)), PBRS_K((k_extend<false, 31u>)),
-#endif
-#ifdef PBRS_DEV_OVERRIDES
-        PBRS_K((k_extend<false, 68u>)), PBRS_K((k_extend<false, 69u>)), PBRS_K((k_extend<false, 70u>)), PBRS_K((k_extend<false, 71u>)),
-        PBRS_K((k_extend<false, 76u>)), PBRS_K((k_extend<false, 77u>)), PBRS_K((k_extend<false, 78u>)), PBRS_K((k_extend<false, 79u>)),
-        PBRS_K((k_shadow<false, 68u>)), PBRS_K((k_shadow<false, 69u>)), PBRS_K((k_shadow<false, 76u>)), PBRS_K((k_shadow<false, 77u>)),
-        PBRS_K((k_extend<false, 36u>)), PBRS_K((k_extend<false, 37u>)), PBRS_K((k_extend<false, 38u>)), PBRS_K((k_extend<false, 39u>)),
-        PBRS_K((k_extend<false, 44u>)), PBRS_K((k_extend<false, 45u>)), PBRS_K((k_extend<false, 46u>)), PBRS_K((k_extend<false, 47u>)),
-        PBRS_K((k_shadow<false, 36u>)), PBRS_K((k_shadow<false, 37u>)), PBRS_K((k_shadow<false, 44u>)), PBRS_K((k_shadow<false, 45u>)),
-#endif
-        PBRS_K((k_shadow<false, 20u>)), PBRS_K((k_shadow<false, 21u>)), PBRS_K((k_shadow<false, 28u>)), PBRS_K((k_shadow<false, 29u>))};
-#undef PBRS_K
+    };
+    for (uint32_t f = 0; f < kFeatCombos; ++f) {
+        if (extend_fns()[f]) traversal_kernels.push_back(reinterpret_cast<const void*>(extend_fns()[f]));
+        if (shadow_fns()[f]) traversal_kernels.push_back(reinterpret_cast<const void*>(shadow_fns()[f]));
+    }
     for (const void* k : traversal_kernels) HIPCHK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     if (c->device < 64) g_kernel_cfg_done[c->device] = true;
     return PBRS_OK;
@@ -974,7 +809,9 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
          hipMalloc(reinterpret_cast<void**>(&c->nonfinite), sizeof(unsigned long long)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&c->bounce_acc), (2 * PBRS_STATS_MAX_BOUNCES + 2) * sizeof(unsigned long long)) == hipSuccess &&
          hipMemset(c->bounce_acc, 0, (2 * PBRS_STATS_MAX_BOUNCES + 2) * sizeof(unsigned long long)) == hipSuccess &&
-         hipMemset(c->nonfinite, 0, sizeof(unsigned long long)) == hipSuccess;
+         hipMemset(c->nonfinite, 0, sizeof(unsigned long long)) == hipSuccess &&
+         hipHostMalloc(reinterpret_cast<void**>(&c->split_host), 2 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
+         hipEventCreateWithFlags(&c->split_ev, hipEventDisableTiming) == hipSuccess;
     ok = ok && configure_kernels(c) == PBRS_OK;
     if (!ok) {
         pbrs_destroy(c);
@@ -994,6 +831,8 @@ void pbrs_destroy(pbrs_ctx* c) {
     if (c->gcnt) (void)hipFree(c->gcnt);
     if (c->nonfinite) (void)hipFree(c->nonfinite);
     if (c->bounce_acc) (void)hipFree(c->bounce_acc);
+    if (c->split_host) (void)hipHostFree(c->split_host);
+    if (c->split_ev) (void)hipEventDestroy(c->split_ev);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -1008,6 +847,12 @@ const char* pbrs_last_error(const pbrs_ctx* c) { return c ? c->error.c_str() : "
 int pbrs_set_stream(pbrs_ctx* c, void* hip_stream) {
     if (!c) return PBRS_E_INVALID;
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return PBRS_OK;
+}
+
+int pbrs_set_cache_bytes(pbrs_ctx* c, uint64_t bytes) {
+    if (!c) return PBRS_E_INVALID;
+    c->cache_bytes = bytes ? bytes : (256ull << 20);
     return PBRS_OK;
 }
 
@@ -1134,9 +979,23 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     free_scene(c);
     DevScene S{};
     int rc;
-    uint32_t wide_levels = 0;  // wide nodes on the longest way down a BLAS
-    bool cnodes_ok = false;    // every BLAS has its compressed records (device/wide.h; developer builds)
-    (void)cnodes_ok;
+    // The division-free box test (device/traverse.h) is exact when every node coordinate b is finite,
+    // |b| <= 2^40 and (b == 0 or |b| >= 2^-20); otherwise every lane uses the literal divisions.
+    {
+        auto coord_ok = [](float b) {
+            uint32_t u = pn_bits(b) & 0x7fffffffu, e = u >> 23;
+            return u == 0u || (e >= 127u - 20u && e <= 127u + 40u);
+        };
+        bool ok = true;
+        for (uint32_t i = 0; i < d->n_tlas_nodes && ok; ++i)
+            for (int a = 0; a < 3; ++a) ok = ok && coord_ok(d->tlas_nodes[i].min[a]) && coord_ok(d->tlas_nodes[i].max[a]);
+        for (uint32_t i = 0; i < d->n_blas_nodes && ok; ++i)
+            for (int a = 0; a < 3; ++a) ok = ok && coord_ok(d->blas_nodes[i].min[a]) && coord_ok(d->blas_nodes[i].max[a]);
+        S.fast_slab = ok ? 1u : 0u;
+    }
+    uint32_t wide_levels = 0;  // wide nodes on the longest way down a BLAS (0: no wide nodes were built)
+    uint64_t walk_bytes = 0;   // what the walks read: nodes, wide nodes, triangle vertices, instance records
+    size_t n_scene_nodes = 0;  // DevScene::nodes: TLAS + its leaf copies + every BLAS
     {
         // DevScene::nodes: the TLAS, then its leaves alone in pre-order when the TLAS is small (the shared scan), then every
         // BLAS, in one array with absolute links — a walk reads nodes + index whatever tree it is in.
@@ -1154,6 +1013,8 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             if (!(nodes[i].b & PBRS_LEAF_FLAG)) nodes[i].a += (uint32_t)blas_off;  // right child; the left one is i + 1
         if (nodes.size() * sizeof(pbrs_node) >= (1ull << 32)) return fail(c, PBRS_E_LIMIT, "too many BVH nodes (the walks address them with 32-bit byte offsets)");
         if ((rc = upload(c, nodes.data(), nodes.size(), &S.nodes))) return rc;
+        n_scene_nodes = nodes.size();
+        walk_bytes = nodes.size() * sizeof(pbrs_node) + (uint64_t)d->n_triangles * sizeof(pbrs_tri_verts) + (uint64_t)d->n_instances * sizeof(pbrs_instance);
         std::vector<pbrs_instance> inst(d->instances, d->instances + d->n_instances);
         // Shading classes: one per distinct lobe signature among the materials (class 0: no lobes — emitters — and misses)
         std::vector<uint32_t> mat_class(d->n_materials, 0u);
@@ -1198,75 +1059,36 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             if (linear_identity) in.flags |= PBRS_INSTANCE_TRANSLATION;
         }
         // Four-wide nodes over every BLAS a mesh instance enters (device/wide.h): pad[1] of the device copy of the instance is
-        // the wide node of its root, PBRS_WREF_NONE where the mesh is a single leaf.
-        {
+        // the wide node of its root, PBRS_WREF_NONE where the mesh is a single leaf.  Built and uploaded only for scenes whose
+        // k_shadow can walk them: a scanned TLAS and coordinates inside the guarded range of the division-free box test (the
+        // deciding PBRS_WIDE_MIN_LEVELS is known once they are built).  A wide array of 4 GiB or more (32-bit byte offsets) is not
+        // an error: the scene keeps the binary walks.
+        for (pbrs_instance& in : inst) in.pad[1] = PBRS_WREF_NONE;
+        S.wide_cap = 4u;
+        if (scan && S.fast_slab != 0u) {
             std::vector<pbrs_wnode> wide;
             std::map<uint32_t, uint32_t> wide_of_root;
             uint32_t levels = 0;
             for (pbrs_instance& in : inst) {
-                in.pad[1] = PBRS_WREF_NONE;
                 if (in.shape_kind != PBRS_SHAPE_MESH || (nodes[in.blas_root].b & PBRS_LEAF_FLAG)) continue;
                 auto it = wide_of_root.find(in.blas_root);
                 if (it == wide_of_root.end()) it = wide_of_root.emplace(in.blas_root, build_wide(nodes, in.blas_root, wide, 0u, levels)).first;
                 in.pad[1] = it->second;
             }
-            if (wide.size() * sizeof(pbrs_wnode) >= (1ull << 32)) return fail(c, PBRS_E_LIMIT, "too many BVH nodes (wide nodes are addressed with 32-bit byte offsets)");
-            const pbrs_wnode* dev = nullptr;
-            if ((rc = upload(c, wide.data(), wide.size(), &dev))) return rc;
-            S.wnodes = dev;
-            // a node step pushes up to three survivors per level; deeper stacks than PBRS_WIDE_STACK_MAX entries are not given LDS:
-            // a ray that would need one (none on the BASELINE scenes) is traced by the binary-walk kernel instead
-            S.wide_cap = std::max(4u, std::min(3u * levels + 1u, (uint32_t)PBRS_WIDE_STACK_MAX));
-            wide_levels = levels;
-        }
-#ifdef PBRS_DEV_OVERRIDES  // (developer builds: the shipped library runs neither walk and does not spend upload time and HBM on them)
-        // Pair nodes over the same trees (device/wide.h): a walk pushes at most one entry per level above the deepest pair node
-        {
-            std::vector<pbrs_pnode> pairs;
-            std::vector<uint32_t> proot(inst.size(), PBRS_WREF_NONE);
-            std::map<uint32_t, uint32_t> pair_of_root;
-            uint32_t levels = 0;
-            for (size_t i = 0; i < inst.size(); ++i) {
-                const pbrs_instance& in = inst[i];
-                if (in.shape_kind != PBRS_SHAPE_MESH || (nodes[in.blas_root].b & PBRS_LEAF_FLAG)) continue;
-                auto it = pair_of_root.find(in.blas_root);
-                if (it == pair_of_root.end()) it = pair_of_root.emplace(in.blas_root, build_pair(nodes, in.blas_root, pairs, 0u, levels)).first;
-                proot[i] = it->second;
+            const bool use = levels >= PBRS_WIDE_MIN_LEVELS && wide.size() * sizeof(pbrs_wnode) < (1ull << 32);
+            if (use) {
+                const pbrs_wnode* dev = nullptr;
+                if ((rc = upload(c, wide.data(), wide.size(), &dev))) return rc;
+                S.wnodes = dev;
+                walk_bytes += wide.size() * sizeof(pbrs_wnode);
+                // a node step pushes up to three survivors per level; deeper stacks than PBRS_WIDE_STACK_MAX entries are not given LDS:
+                // a ray that would need one (none on the BASELINE scenes) is traced by the binary-walk kernel instead
+                S.wide_cap = std::max(4u, std::min(3u * levels + 1u, (uint32_t)PBRS_WIDE_STACK_MAX));
+                wide_levels = levels;
+            } else {
+                for (pbrs_instance& in : inst) in.pad[1] = PBRS_WREF_NONE;
             }
-            if (pairs.size() * sizeof(pbrs_pnode) >= (1ull << 32)) return fail(c, PBRS_E_LIMIT, "too many BVH nodes (pair nodes are addressed with 32-bit byte offsets)");
-            const pbrs_pnode* dev = nullptr;
-            if ((rc = upload(c, pairs.data(), pairs.size(), &dev))) return rc;
-            c->pnodes = reinterpret_cast<const pbrs_wnode*>(dev);
-            if ((rc = upload(c, proot.data(), proot.size(), &c->proot))) return rc;
-            c->pair_cap = std::max(2u, std::min(levels, (uint32_t)PBRS_PAIR_STACK_MAX));
         }
-        // Compressed records of every BLAS a mesh instance enters (device/wide.h), on the grid of that BLAS's root
-        {
-            std::vector<pbrs_cnode> cn(nodes.size(), pbrs_cnode{0u, 0u, 0u, PBRS_CNODE_LEAF});
-            std::vector<pbrs_cframe> frames(inst.size(), pbrs_cframe{});
-            std::map<uint32_t, pbrs_cframe> frame_of_root;
-            cnodes_ok = nodes.size() <= PBRS_CNODE_CHILD_MASK;  // a record links with 29 bits
-            for (size_t i = 0; cnodes_ok && i < inst.size(); ++i) {
-                const pbrs_instance& in = inst[i];
-                if (in.shape_kind != PBRS_SHAPE_MESH) continue;
-                auto it = frame_of_root.find(in.blas_root);
-                if (it == frame_of_root.end()) {
-                    pbrs_cframe f{};
-                    cnodes_ok = build_cnodes(nodes, in.blas_root, cn, f) && cnodes_ok;
-                    it = frame_of_root.emplace(in.blas_root, f).first;
-                }
-                frames[i] = it->second;
-            }
-            if ((rc = upload(c, cn.data(), cn.size(), &S.cnodes))) return rc;
-            if ((rc = upload(c, frames.data(), frames.size(), &S.cframes))) return rc;
-            // A walk keeps the child it visits next in a register and pushes the other one: at most one entry per level.  Six blocks of
-            // a traversal kernel fit a CU's LDS with 26 rows each (k_extend: the entry distances of the scanned TLAS leaves take
-            // n_flat of them); the rare ray that wants more than the rest goes to the binary walk.
-            const uint32_t rows6 = (uint32_t)(kLdsBytesPerCU / 6 / (kBlock * sizeof(uint32_t)));
-            c->cnode_cap_s = std::max(2u, std::min(max_blas_height, rows6));
-            c->cnode_cap_x = std::max(2u, std::min(max_blas_height, std::max(rows6 - std::min(rows6, S.n_flat), 16u)));
-        }
-#endif
         if ((rc = upload(c, inst.data(), inst.size(), &S.inst))) return rc;
     }
     if ((rc = upload(c, d->shapes, d->n_shapes, &S.shapes))) return rc;
@@ -1289,25 +1111,14 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     std::memcpy(S.env, d->env_constant, sizeof S.env);
     // Scene::has_env_light for EnvLight::Constant (scene/src/lib.rs:96-102): !c.is_black()
     S.has_env = (d->env_kind != PBRS_ENV_CONSTANT || !(S.env[0] <= 0.0f && S.env[1] <= 0.0f && S.env[2] <= 0.0f)) ? 1u : 0u;
-    // The f64-reciprocal box test (device/traverse.h) is exact when every node coordinate b is finite,
-    // |b| <= 2^40 and (b == 0 or |b| >= 2^-20); otherwise every lane uses the literal divisions.
-    {
-        auto coord_ok = [](float b) {
-            uint32_t u = pn_bits(b) & 0x7fffffffu, e = u >> 23;
-            return u == 0u || (e >= 127u - 20u && e <= 127u + 40u);
-        };
-        bool ok = true;
-        for (uint32_t i = 0; i < d->n_tlas_nodes && ok; ++i)
-            for (int a = 0; a < 3; ++a) ok = ok && coord_ok(d->tlas_nodes[i].min[a]) && coord_ok(d->tlas_nodes[i].max[a]);
-        for (uint32_t i = 0; i < d->n_blas_nodes && ok; ++i)
-            for (int a = 0; a < 3; ++a) ok = ok && coord_ok(d->blas_nodes[i].min[a]) && coord_ok(d->blas_nodes[i].max[a]);
-        S.fast_slab = ok ? 1u : 0u;
-    }
     S.refill_below = max_blas_height >= PBRS_LONG_WALK_HEIGHT ? PBRS_REFILL_BELOW_LONG : PBRS_REFILL_BELOW_SHORT;
     if (const char* e = dev_env("PBRS_REFILL_BELOW")) S.refill_below = (uint32_t)std::atoi(e);  // developer override (A/B timing)
     // long walks: the levels a ray actually walks — the deepest BLAS, plus the TLAS where it is not scanned
     c->long_walks = (S.n_flat ? 0u : tlas_levels) + max_blas_height >= PBRS_LONG_WALK_HEIGHT;
     if (const char* e = dev_env("PBRS_LONG_WALKS")) c->long_walks = std::atoi(e) != 0;  // developer override (A/B timing)
+    // lean further node steps where the walks' arrays live in the caches, full ones where their fetches go to HBM (kernels.h)
+    c->walk_bytes = walk_bytes;
+    c->full_steps = walk_bytes > c->cache_bytes;
     // the leaf copies serve k_shadow up to PBRS_FLAT_TLAS_MAX_ANYHIT instances, k_extend up to PBRS_FLAT_TLAS_MAX
     c->shadow_flat = S.n_flat != 0u;
     const uint32_t flat_feature = (S.n_flat != 0u && d->n_instances <= PBRS_FLAT_TLAS_MAX) ? PBRS_FEAT_FLAT_TLAS : 0u;
@@ -1318,29 +1129,13 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     // k_shadow gains (C4: 250 -> 236 ms per frame at five waves per SIMD); k_extend, whose wide walk needs 117 registers (four
     // waves per SIMD, or 72 bytes of spills at five), loses against the binary walk at six (459 -> 506 ms) and keeps the binary
     // walk: its wide kernels exist in developer builds only (PBRS_WIDE bit 0).
-    const bool wide_ok = S.fast_slab != 0u && wide_levels >= PBRS_WIDE_MIN_LEVELS;
+    const bool wide_ok = S.fast_slab != 0u && S.wnodes != nullptr && wide_levels >= PBRS_WIDE_MIN_LEVELS;
     c->wide_extend = false;
     c->wide_shadow = c->shadow_flat && wide_ok;
-    c->pair_extend = c->pair_shadow = false;
-    c->cnode_extend = c->cnode_shadow = false;
-    c->grid_extend = c->grid_shadow = false;
 #ifdef PBRS_DEV_OVERRIDES
     if (const char* e = dev_env("PBRS_WIDE")) {  // developer override (A/B timing): bit 0 k_extend, bit 1 k_shadow
         c->wide_extend = flat_feature != 0u && wide_ok && (std::atoi(e) & 1);
         c->wide_shadow = c->wide_shadow && (std::atoi(e) & 2);
-    }
-    if (const char* e = dev_env("PBRS_GRID")) {  // the binary walks on the compressed records: bit 0 k_extend, bit 1 k_shadow
-        c->grid_extend = flat_feature != 0u && S.fast_slab != 0u && cnodes_ok && (std::atoi(e) & 1);
-        c->grid_shadow = c->shadow_flat && S.fast_slab != 0u && cnodes_ok && (std::atoi(e) & 2);
-        if (c->grid_shadow) c->wide_shadow = false;
-    }
-    if (const char* e = dev_env("PBRS_CNODE")) {  // ... over the compressed records: bit 0 k_extend, bit 1 k_shadow
-        if (flat_feature != 0u && S.fast_slab != 0u && cnodes_ok && (std::atoi(e) & 1)) c->wide_extend = c->cnode_extend = true;
-        if (c->shadow_flat && S.fast_slab != 0u && cnodes_ok && (std::atoi(e) & 2)) c->wide_shadow = c->cnode_shadow = true;
-    }
-    if (const char* e = dev_env("PBRS_PAIR")) {  // ... the walks over pair nodes instead: bit 0 k_extend, bit 1 k_shadow
-        if (flat_feature != 0u && wide_ok && (std::atoi(e) & 1)) c->wide_extend = c->pair_extend = true;
-        if (c->shadow_flat && wide_ok && (std::atoi(e) & 2)) c->wide_shadow = c->pair_shadow = true;
     }
 #endif
     for (uint32_t i = 0; i < d->n_instances; ++i) {
@@ -1378,13 +1173,29 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         if (const char* e = dev_env("PBRS_SHADE_SPEC")) spec &= (uint32_t)std::atoi(e);  // developer override (A/B timing): a mask
         c->shade_spec = spec;
     }
+    // The arrays the walks read, staged in every block's LDS (kernels.h, stage_scene) where they fit next to the stack rows with
+    // eight blocks to a CU: scenes of a few KB whose walks are short (no wide nodes, lean-step choice irrelevant).
+    {
+        const size_t stack_bytes = (size_t)depth * kBlock * sizeof(uint32_t);
+        const size_t scene_bytes = n_scene_nodes * sizeof(pbrs_node) + (size_t)d->n_triangles * sizeof(pbrs_tri_verts) + (size_t)d->n_instances * sizeof(pbrs_instance) +
+                                   (size_t)d->n_shapes * sizeof(pbrs_shape);
+        c->lds_scene = !c->wide_shadow && !c->wide_extend && !c->full_steps && stack_bytes + scene_bytes <= kLdsBytesPerCU / 8;
+        if (const char* e = dev_env("PBRS_LDS_SCENE")) c->lds_scene = c->lds_scene && std::atoi(e) != 0;  // developer override (A/B timing)
+        c->lds_scene_bytes = c->lds_scene ? scene_bytes : 0;
+        S.lds_off_words = depth * kBlock;
+        S.lds_nodes = c->lds_scene ? (uint32_t)n_scene_nodes : 0u;
+        S.lds_tris = c->lds_scene ? d->n_triangles : 0u;
+        S.lds_inst = c->lds_scene ? d->n_instances : 0u;
+        S.lds_shapes = c->lds_scene ? d->n_shapes : 0u;
+    }
     c->S = S;
     c->textured = textured;
     c->fourier = fourier;
     c->has_vis_records = vis_records;
     c->stack_depth = depth;
     c->has_scene = true;
-    c->split_decision = 0;
+    c->split_decision = 0;  // (the stream was synchronised above: no probe of the previous scene is in flight)
+    c->split_probe_in_flight = false;
     return PBRS_OK;
 }
 
@@ -1427,9 +1238,10 @@ int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const flo
     float* d_t = nullptr;
     pbrs_hit_record* d_h = nullptr;
     uint8_t* d_occ = nullptr;
+    uint32_t* d_info = nullptr;
     int rc = PBRS_OK;
     auto cleanup = [&]() {
-        (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_h); (void)hipFree(d_occ);
+        (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_h); (void)hipFree(d_occ); (void)hipFree(d_info);
     };
 #define TRY(expr)                                                                  \
     do {                                                                           \
@@ -1452,6 +1264,8 @@ int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const flo
     TRY(hipMalloc(reinterpret_cast<void**>(&d_t), (size_t)n * 4));
     if (hits_out) TRY(hipMalloc(reinterpret_cast<void**>(&d_h), (size_t)n * sizeof(pbrs_hit_record)));
     if (occluded_out) TRY(hipMalloc(reinterpret_cast<void**>(&d_occ), (size_t)n));
+    TRY(hipMalloc(reinterpret_cast<void**>(&d_info), 2 * sizeof(uint32_t)));
+    TRY(hipMemsetAsync(d_info, 0, 2 * sizeof(uint32_t), c->stream));
     TRY(hipMemcpyAsync(d_o, h_o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     TRY(hipMemcpyAsync(d_d, h_d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     TRY(hipMemcpyAsync(d_t, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -1461,15 +1275,35 @@ int pbrs_intersect_rays(pbrs_ctx* c, uint32_t n, const float* origins, const flo
         const uint32_t rows = std::max(c->stack_depth, c->S.wide_cap);
         const size_t lds = (size_t)(rows + c->S.n_flat) * kBlock * sizeof(uint32_t);
         const dim3 grid(std::min<uint32_t>((n + kBlock - 1) / kBlock, kPersistentBlocks));
-        if (c->wide_extend && c->wide_shadow) hipLaunchKernelGGL(k_intersect_rays<true>, grid, dim3(kBlock), lds, c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ, rows);
-        else hipLaunchKernelGGL(k_intersect_rays<false>, grid, dim3(kBlock), lds, c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ, rows);
+        // each query through the walk its stage runs in the pipeline (run_pass): occlusion through the four-wide any-hit walk whenever
+        // k_shadow takes it, closest hits through the binary walk (the four-wide closest walk exists in developer builds only)
+        c->last_intersect = pbrs_intersect_info{c->wide_shadow ? 1u : 0u, c->wide_extend ? 1u : 0u, 0u, 0u};
+#define PBRS_LAUNCH_RAYS(WC, WA) hipLaunchKernelGGL((k_intersect_rays<WC, WA>), grid, dim3(kBlock), lds, c->stream, c->S, n, d_o, d_d, d_t, d_h, d_occ, d_info)
+#ifdef PBRS_DEV_OVERRIDES
+        if (c->wide_extend && c->wide_shadow) PBRS_LAUNCH_RAYS(true, true);
+        else if (c->wide_extend) PBRS_LAUNCH_RAYS(true, false);
+        else
+#endif
+        if (c->wide_shadow) PBRS_LAUNCH_RAYS(false, true);
+        else PBRS_LAUNCH_RAYS(false, false);
+#undef PBRS_LAUNCH_RAYS
     }
     TRY(hipGetLastError());
     if (hits_out) TRY(hipMemcpyAsync(hits_out, d_h, (size_t)n * sizeof(pbrs_hit_record), hipMemcpyDeviceToHost, c->stream));
     if (occluded_out) TRY(hipMemcpyAsync(occluded_out, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    uint32_t slow[2] = {0u, 0u};
+    TRY(hipMemcpyAsync(slow, d_info, sizeof slow, hipMemcpyDeviceToHost, c->stream));
     TRY(hipStreamSynchronize(c->stream));
+    c->last_intersect.slow_any = slow[0];
+    c->last_intersect.slow_closest = slow[1];
     cleanup();
     return rc;
+}
+
+int pbrs_last_intersect_info(const pbrs_ctx* c, pbrs_intersect_info* out) {
+    if (!c || !out) return PBRS_E_INVALID;
+    *out = c->last_intersect;
+    return PBRS_OK;
 }
 
 int pbrs_camera_rays(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params* p, uint32_t sample_index, float* origins_out, float* dirs_out) {

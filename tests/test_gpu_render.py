@@ -597,7 +597,9 @@ def test_wide_walk_kernels_and_their_slow_list_match_oracle(gpu_ctx):
     AND by a distant light that shines straight down: `target.pos - world_radius * 2 * casting_dir - target.pos` is exactly zero
     in x and z (light/src/lib.rs:77-81), so every shadow ray towards it is outside the guarded range of the division-free box
     test — the wide-walk kernel hands those to the binary-walk kernel through its slow list, the others it traces itself.  Image,
-    ray counts and invalid samples equal the oracle's; so do hit records and occlusion of synthetic rays with zero components."""
+    ray counts and invalid samples equal the oracle's; so do hit records and occlusion of synthetic rays with zero components,
+    denormal components and origins outside the guarded range: the harness sends occlusion queries through the four-wide any-hit
+    walk k_shadow runs for this scene (asserted through pbrs_last_intersect_info) and counts the rays that walk refused."""
     sb, c = scenes.build_config("c4", width=192, height=96, nx=128, nz=128)
     sb.distant_light((0.0, -1.0, 0.0), (1.5, 1.4, 1.3), 700.0)
     hs = pbrs_amd.HostScene(sb)
@@ -612,7 +614,8 @@ def test_wide_walk_kernels_and_their_slow_list_match_oracle(gpu_ctx):
     assert (bits(cnt) == bits(ref)).all()
     assert stc["closest_rays"] == ost["closest_rays"] and stc["shadow_rays"] == ost["shadow_rays"]
     assert st["invalid_samples"] == ost["nonfinite_samples"]
-    # rays through the parity harness (the wide walks where the pipeline uses them): axis-parallel directions among random ones
+    # rays through the parity harness (every query through the walk its stage runs in the pipeline): axis-parallel, denormal and
+    # huge direction components and tiny origin components (outside the guarded range: the wide walk's slow hand-off) among random ones
     rng = np.random.default_rng(4)
     n = 4096
     o = np.stack([rng.uniform(-90, 90, n), rng.uniform(20, 80, n), rng.uniform(20, 380, n)], axis=1).astype(np.float32)
@@ -620,9 +623,44 @@ def test_wide_walk_kernels_and_their_slow_list_match_oracle(gpu_ctx):
     d[::7, 0] = 0.0
     d[::11, 2] = 0.0
     d[::5] = (0.0, -1.0, 0.0)
+    d[3::13, 0] = 1e-42          # denormal
+    d[4::17, 1] *= np.float32(2.0 ** 50)   # beyond 2^40
+    o[6::19, 0] = 1e-30          # tiny but non-zero origin component
+    refused = (d == 0).any(axis=1) | (np.abs(d) < 2.0 ** -40).any(axis=1) | (np.abs(d) > 2.0 ** 40).any(axis=1) | ((o != 0) & (np.abs(o) < 2.0 ** -60)).any(axis=1)
     tmax = np.where(rng.uniform(size=n) < 0.5, np.inf, rng.uniform(10, 300, n)).astype(np.float32)
     gh, gocc = gpu_ctx.intersect(o, d, tmax)
+    info = gpu_ctx.last_intersect_info()
+    assert info["wide_any"] == 1, info                      # occlusion went through AnyWalkW (tlas_any_wide), as in k_shadow
+    assert info["slow_any"] >= int(refused.sum()) > 500, (info, int(refused.sum()))  # ... and its hand-off took at least the rays outside the range
+    assert info["slow_any"] < n // 2, info                  # ... while most rays stayed on the wide walk
     oh, oocc, _ = osc.intersect(o, d, tmax)
     assert (gocc == oocc).all()
+    assert 0.05 < gocc.mean() < 0.95
     assert (gh["inst"] == oh["inst"]).all() and (bits(gh["t"]) == bits(oh["t"])).all() and (gh["prim"] == oh["prim"]).all()
     assert (gh["inst"] != 0xffffffff).mean() > 0.3
+
+
+def test_scene_beyond_the_cache_budget_takes_the_full_step_kernels(gpu_ctx):
+    """pbrs_upload_scene chooses a round's further node steps per scene (kernels.h): lean ones where the arrays the walks read fit
+    the last-level cache, full ones (PBRS_FEAT_FULL_STEPS) where they do not — c4xl's 2.2 GB against the 256 MiB Infinity Cache.
+    The suite does not ship a 2 GB scene: the cache budget is lowered instead (pbrs_set_cache_bytes), the same deep terrain is
+    rendered through both sets of kernels and both frames equal the oracle's bit for bit."""
+    FULL = 32
+    sb, c = scenes.build_config("c4", width=160, height=96, nx=128, nz=128)
+    hs = pbrs_amd.HostScene(sb)
+    ref, ost = OracleScene(sb).render(2, 2, c["depth"], 21)
+    try:
+        gpu_ctx.set_cache_bytes(1 << 20)  # the scene's nodes and triangles are a few MB
+        gpu_ctx.upload(hs)
+        full, st_full = gpu_ctx.render(2, 2, c["depth"], 21)
+        assert st_full["kernel_features_extend"] & FULL and st_full["kernel_features_shadow"] & FULL, st_full
+        assert st_full["kernel_features_extend"] & 8 and st_full["kernel_features_shadow"] & 16  # several node steps per round; wide k_shadow
+    finally:
+        gpu_ctx.set_cache_bytes(0)
+    gpu_ctx.upload(hs)
+    lean, st_lean = gpu_ctx.render(2, 2, c["depth"], 21)
+    assert not (st_lean["kernel_features_extend"] & FULL) and not (st_lean["kernel_features_shadow"] & FULL), st_lean
+    assert np.isfinite(ref).all()
+    assert (bits(full) == bits(ref)).all()
+    assert (bits(lean) == bits(ref)).all()
+    assert st_full["invalid_samples"] == st_lean["invalid_samples"] == ost["nonfinite_samples"]
