@@ -211,12 +211,21 @@ class Workload:
                     stage_ms[k] += st[k]
                 for k in launches:
                     launches[k] += st[k]
+        own_wall = time.perf_counter() - t0
         self.barrier()
         elapsed = time.perf_counter() - t0
         if timed_frame is not None:
             timed_frame = np.array(timed_frame, copy=True)  # after the clock has stopped: the host buffers are reused by the frames that follow
         gather_ms = self.gather_s / steps * 1e3
+        # what each rank did, so that a scaling curve explains itself: rows / bands it owns, its own wall time for the K frames
+        # (its GPU work + hand-over, before the closing barrier) and the HIP-event time of its frames
+        mine = {"rank": rank, "rows": int(self.my_rows), "bands": int(-(-self.my_rows // self.tiling.BAND_ROWS)),
+                "gpu_ms_per_step": float(sum(st["ms_total"] for st in per_frame if st is not None) / steps),
+                "own_wall_ms_per_step": float(own_wall / steps * 1e3), "handover_ms_per_step": float(gather_ms)}
+        per_rank = [mine]
         if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
             t = torch.tensor([elapsed, gather_ms], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, gather_ms = float(t[0].item()), float(t[1].item())
@@ -232,11 +241,11 @@ class Workload:
             counts = tc.numpy()
         if rank != 0:
             return None
+        W, H, sx, sy, depth, spp = self.W, self.H, self.sx, self.sy, self.depth, self.sx * self.sy
         # the instrumented frame is the same frame from other kernel instantiations: it must be the timed one bit for bit
         frames_agree = bool((np.isnan(frame) == np.isnan(timed_frame)).all() and
                             (frame.view(np.uint32)[~np.isnan(frame)] == timed_frame.view(np.uint32)[~np.isnan(timed_frame)]).all())
 
-        W, H, sx, sy, depth, spp = self.W, self.H, self.sx, self.sy, self.depth, self.sx * self.sy
         samples_per_step = float(W) * H * spp
         assert counts[2] == samples_per_step, (counts, samples_per_step)
         rays_per_step = counts[0] + counts[1]
@@ -246,18 +255,27 @@ class Workload:
         # this workload are read from profiles/ (tools/round_artifacts.sh -> tools/traffic_from_pmc.py), full-size runs only.
         traffic_doc, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", f"latest_traffic_{self.name}.json")
-        if os.path.exists(tpath) and world == 1 and self.full_size and not self.args.samples_per_pass:
+        if os.path.exists(tpath) and world == 1 and self.args.integrator == "path" and not self.args.samples_per_pass:
             with open(tpath) as f:
                 traffic_doc = json.load(f)
             traffic_src = os.path.relpath(tpath, ROOT)
-            # per-launch figures only carry over when a launch is the same size: same number of passes per frame
-            if traffic_doc.get("geometry", {}).get("passes") not in (None, cst["passes"]):
-                traffic_doc, traffic_src = None, f"{traffic_src} ignored: measured at {traffic_doc['geometry']['passes']} passes per frame, this run has {cst['passes']}"
+            geo = traffic_doc.get("geometry", {})
+            # per-launch figures only carry over when a launch is the same size: the same frame (pixels, spp — a full-size config, or
+            # the stated slice C5 rides along on) cut into the same number of passes
+            if (geo.get("pixels"), geo.get("spp")) != (W * H, spp):
+                traffic_doc, traffic_src = None, f"{traffic_src} ignored: measured on {geo.get('pixels')} pixels x {geo.get('spp')} spp, this run has {W * H} x {spp}"
+            elif geo.get("passes") not in (None, cst["passes"]):
+                traffic_doc, traffic_src = None, f"{traffic_src} ignored: measured at {geo['passes']} passes per frame, this run has {cst['passes']}"
             # ... and when the counters were measured on the kernels being timed: the file carries a hash of the sources
             elif traffic_doc.get("source_hash") != roofline.source_hash():
                 traffic_doc, traffic_src = None, (f"{traffic_src} ignored: measured on sources {traffic_doc.get('source_hash')} "
                                                   f"(git {traffic_doc.get('git_head')}), this run is built from {roofline.source_hash()}")
-        rep = roofline.stage_report(cst, times, scene_nbytes=self.hs.nbytes, traffic_doc=traffic_doc)
+        isa_doc = None
+        ipath = os.path.join(ROOT, "profiles", "latest_isa_mix.json")
+        if os.path.exists(ipath):
+            with open(ipath) as f:
+                isa_doc = json.load(f)
+        rep = roofline.stage_report(cst, times, scene_nbytes=self.hs.nbytes, traffic_doc=traffic_doc, isa_doc=isa_doc)
         dom_name, dom = roofline.dominant(rep)
         trav = roofline.traversal(rep)
         # the queue/state bytes are a model: a fraction above 1 says the model is off, which the line reports instead of hiding
@@ -295,6 +313,8 @@ class Workload:
             "frame_mean_radiance": [float(x) for x in timed_frame.reshape(-1, 3).mean(axis=0)],
             "parity_window": window,
             "gather_ms": gather_ms,
+            "per_rank": per_rank,
+            "band_imbalance": max(r["rows"] for r in per_rank) / (sum(r["rows"] for r in per_rank) / len(per_rank)),
             "roofline_inconsistent": inconsistent or False,
             "roofline": {
                 "bound": roofline.bound_of(dom), "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
@@ -303,12 +323,15 @@ class Workload:
                 "queue_state_bytes_per_launch": dom["queue_state_bytes_per_launch"], "scene_miss_bytes_per_launch": dom["scene_miss_bytes_per_launch"],
                 "scene_bytes_per_launch": dom["scene_bytes_per_launch"], "cache_work_rate_GBps": dom["cache_work_rate_GBps"],
                 "ms_per_launch": dom["ms_per_launch"], "launches_per_step": dom["launches"],
+                "bound_shares": roofline.bound_shares(dom),
                 "valu_issue_frac": dom.get("valu_issue_frac"), "valu_issue_frac_min": dom.get("valu_issue_frac_min"),
-                "valu_lanes_active": dom.get("valu_lanes_active"),
+                "valu_issue_frac_nominal": dom.get("valu_issue_frac_nominal"), "valu_32bit_encoding_share": dom.get("valu_32bit_encoding_share"),
+                "salu_issue_frac": dom.get("salu_issue_frac"), "valu_lanes_active": dom.get("valu_lanes_active"),
                 "l1_access_frac": dom.get("l1_access_frac"), "l1_accesses_per_launch": dom.get("l1_accesses_per_launch"),
                 "ta_busy_share": dom.get("ta_busy_share"), "td_busy_share": dom.get("td_busy_share"),
-                "note": "rank 0's kernels, the stage with the most time per frame; bound = the resource the kernel fills the largest share of: "
-                        "hbm, valu_issue or l1_access (frac stays the HBM fraction); l1_access_frac = L1 accesses per launch (one per lane of "
+                "note": "rank 0's kernels, the stage with the most time per frame; bound = the resource the kernel fills the largest share of "
+                        "(bound_shares, every share <= 1): hbm (measured L2 -> fabric traffic where a counter file applies, else the model), valu_issue, "
+                        "salu_issue, l1_access or td_busy (frac stays the HBM fraction); l1_access_frac = L1 accesses per launch (one per lane of "
                         "a load whose lanes name different lines, whatever its width: rocprofv3 TCP_TOTAL_CACHE_ACCESSES, offline) over 256 CUs x "
                         "one access per cycle x the live kernel time x 2.4 GHz; ta / td_busy_share = busy cycles of the texture address / data "
                         "units over the kernel's cycles (offline); achieved = (queue/state bytes that must "
@@ -317,10 +340,11 @@ class Workload:
                         "per launch from separate rocprofv3 TCC passes (Infinity-Cache hits included: an upper bound of HBM bytes), measured "
                         "offline on the same sources (source hash checked), see profiles/; "
                         "cache_work_rate prices every node / triangle visit at record size and is NOT an HBM figure; valu_issue_frac = "
-                        "share of the chip's vector issue slots the kernel fills (wave-level VALU instructions per launch from the SQ "
-                        "pass in profiles/, x the nominal 4 cycles, over 1024 SIMDs x the live kernel time x 2.4 GHz): an upper bound that can pass 1 — "
-                        "32-bit-encoded f32 / integer instructions issue in 2.7 cycles, 64-bit encodings, f64 and conversions in about 4 "
-                        "(tools/microbench/issue_rates.hip); valu_issue_frac_min = the same count at 2.7 cycles each: the true share lies between",
+                        "share of the chip's vector issue slots the kernel fills: wave-level VALU instructions per launch (SQ pass in profiles/) priced "
+                        "at the kernel's static encoding mix (valu_32bit_encoding_share of them at the 2.7 cycles measured for 32-bit encodings, the "
+                        "rest at 4.0: tools/isa_stats.py --json, tools/microbench/issue_rates.hip) over 1024 SIMDs x the live kernel time x 2.4 GHz; "
+                        "valu_issue_frac_nominal / _min = the same count at 4 / at 2.7 cycles each (brackets; the nominal one can pass 1); "
+                        "salu_issue_frac = scalar instructions x 4.25 cycles over the same slots (they issue beside other waves' vector work)",
             },
             "traversal": trav,
             "stages_ms_per_step": times,
@@ -406,6 +430,7 @@ def main():
         }
         for k in ("mrays_per_s", "rays_per_step", "closest_rays_per_step", "shadow_rays_per_step", "shade_events_per_step", "mean_path_length",
                   "rays_per_sample", "paths_at_bounce", "shadow_rays_at_bounce", "invalid_samples", "frame_mean_radiance", "parity_window", "gather_ms",
+                  "per_rank", "band_imbalance",
                   "roofline_inconsistent", "roofline", "traversal", "stages_ms_per_step", "stages"):
             line[k] = result[k]
         if others:

@@ -49,6 +49,13 @@ CLOCK_HZ = 2.4e9        # peak engine clock (same guide); the sustained clock is
 CYCLES_PER_WAVE_VALU = 4
 # ... what the 32-bit-encoded f32 / integer instructions — most of a traversal step — were measured to take (tools/microbench/issue_rates.hip)
 CYCLES_PER_WAVE_VALU_MIN = 2.7
+# The calibrated price (round 4): a kernel's dynamic instruction count (SQ_INSTS_VALU) at the mix of its STATIC code — the share of its
+# vector instructions in a 32-bit encoding (tools/isa_stats.py --json: `_e32` forms without a literal) at 2.7 cycles, the rest (64-bit
+# encodings, DPP, literals, f64, conversions: 3.8-4.4 measured) at 4.0.  The static mix stands in for the dynamic one (the hot loops are
+# most of both); the result is the `valu_issue_frac` the bound is chosen with, the all-4 and all-2.7 figures stay beside it as brackets.
+CYCLES_PER_WAVE_VALU_64BIT = 4.0
+# scalar instructions of a wave issue one at a time, beside the vector work of OTHER waves of the SIMD: 4.2-4.3 cycles each (same microbenchmark)
+CYCLES_PER_WAVE_SALU = 4.25
 N_CU = 256
 L1_ACCESSES_PER_CU_CYCLE = 1.0  # a CU's L1 takes one access (one lane of a load whose lanes name different lines) per cycle,
                                 # whatever the load's width: tools/microbench/gather_rates.hip, 64.6 cycles per 64-lane load
@@ -158,9 +165,28 @@ def kernel_valu(traffic_doc, kernel, stage_launches_per_frame=None):
     return per_launch, lanes
 
 
-def stage_report(counters, times, scene_nbytes=0, traffic_doc=None):
+def static_mix(isa_doc, traffic_doc, kernel):
+    """Share of `kernel`'s vector instructions in a 32-bit encoding: static counts (tools/isa_stats.py --json) of the instantiations the
+    traffic document saw running, weighted by their dynamic instruction counts; None without an ISA document for the same sources."""
+    if not isa_doc or not traffic_doc or isa_doc.get("source_hash") != traffic_doc.get("source_hash"):
+        return None
+    num = den = 0.0
+    for k, v in traffic_doc.get("kernels", {}).items():
+        if not (k == kernel or (k.startswith(kernel + "<") and not k.startswith(kernel + "<true"))) or "valu_insts" not in v:
+            continue
+        st = isa_doc.get("kernels", {}).get(k)
+        if not st or not st.get("valu"):
+            continue
+        w = v["valu_insts"] * v["launches"]
+        num += w * st["valu32"] / st["valu"]
+        den += w
+    return num / den if den else None
+
+
+def stage_report(counters, times, scene_nbytes=0, traffic_doc=None, isa_doc=None):
     """counters: stats dict of an instrumented frame; times: per-frame stage times and launch counts of the timed frames;
-    scene_nbytes: size of the resident scene; traffic_doc: parsed profiles/latest_traffic_<config>.json or None."""
+    scene_nbytes: size of the resident scene; traffic_doc: parsed profiles/latest_traffic_<config>.json or None; isa_doc: parsed
+    profiles/latest_isa_mix.json (static encoding mix per kernel) or None."""
     out = {}
     for stage, (kernel, qfn, sfn, ms_key, launch_key) in STAGES.items():
         ms = float(times[ms_key])
@@ -196,10 +222,19 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None):
             # binds the kernels that HBM does not — a lower bound, the sustained clock being below CLOCK_HZ
             out[stage]["valu_insts_per_launch"] = valu[0]
             out[stage]["valu_lanes_active"] = valu[1]
-            out[stage]["valu_issue_frac"] = valu[0] * CYCLES_PER_WAVE_VALU / (N_SIMD * sec * CLOCK_HZ)
-            # the same count at the cheapest measured issue cost: the true share lies between the two (the nominal figure
-            # passes 1 where most instructions are the 2.7-cycle kind)
+            out[stage]["valu_issue_frac_nominal"] = valu[0] * CYCLES_PER_WAVE_VALU / (N_SIMD * sec * CLOCK_HZ)  # every instruction at 4 cycles: may pass 1
+            # the same count at the cheapest measured issue cost: the true share lies between the two
             out[stage]["valu_issue_frac_min"] = valu[0] * CYCLES_PER_WAVE_VALU_MIN / (N_SIMD * sec * CLOCK_HZ)
+            # ... and at the kernel's static encoding mix: the calibrated figure, the one the bound is chosen with
+            mix = static_mix(isa_doc, traffic_doc, kernel)
+            out[stage]["valu_32bit_encoding_share"] = mix
+            # (no ISA document for these sources: the midpoint of the two prices, and the line says the mix is unknown)
+            cyc = (mix * CYCLES_PER_WAVE_VALU_MIN + (1.0 - mix) * CYCLES_PER_WAVE_VALU_64BIT) if mix is not None else 0.5 * (CYCLES_PER_WAVE_VALU_MIN + CYCLES_PER_WAVE_VALU_64BIT)
+            out[stage]["valu_issue_frac"] = min(valu[0] * cyc / (N_SIMD * sec * CLOCK_HZ), 1.0)
+        salu = kernel_field(traffic_doc, kernel, "salu_insts", launches)
+        if salu is not None and sec > 0:
+            out[stage]["salu_insts_per_launch"] = salu
+            out[stage]["salu_issue_frac"] = min(salu * CYCLES_PER_WAVE_SALU / (N_SIMD * sec * CLOCK_HZ), 1.0)
         l1 = kernel_field(traffic_doc, kernel, "l1_accesses", launches)
         if l1 is not None and sec > 0:
             # share of the L1s' access slots: a load whose 64 lanes name 64 lines is 64 accesses whatever its width, so a walk's
@@ -230,11 +265,19 @@ def traversal(report):
                     "(SURVEY.md §8d) and is served by L2 / Infinity Cache, so it is not comparable with the HBM peak"}
 
 
+def bound_shares(stage_row):
+    """The shares (each <= 1) of the resources a kernel can be bound by: HBM (measured traffic where there is any, else the model),
+    the vector issue slots at the kernel's static encoding mix, the scalar issue slots, the L1s' access slots and the busy share of
+    the texture data path."""
+    hbm = stage_row.get("frac_measured")
+    return {"hbm": min(hbm if hbm is not None else stage_row["frac"], 1.0), "valu_issue": stage_row.get("valu_issue_frac") or 0.0,
+            "salu_issue": stage_row.get("salu_issue_frac") or 0.0, "l1_access": min(stage_row.get("l1_access_frac") or 0.0, 1.0),
+            "td_busy": min(stage_row.get("td_busy_share") or 0.0, 1.0)}
+
+
 def bound_of(stage_row):
-    """The resource the kernel fills the largest share of: "hbm", "valu_issue" (the chip's vector issue slots, an upper bound)
-    or "l1_access" (the L1s' one access per cycle and CU)."""
-    cands = {"hbm": stage_row["frac"], "valu_issue": stage_row.get("valu_issue_frac") or 0.0, "l1_access": stage_row.get("l1_access_frac") or 0.0}
-    return max(cands.items(), key=lambda kv: kv[1])[0]
+    """The resource the kernel fills the largest share of (bound_shares); "hbm" when no counters apply."""
+    return max(bound_shares(stage_row).items(), key=lambda kv: kv[1])[0]
 
 
 def source_hash(root=None):

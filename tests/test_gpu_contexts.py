@@ -110,3 +110,31 @@ def test_the_environment_does_not_change_a_render(monkeypatch):
     assert (bits(img) == bits(ref)).all()
     for k in ("passes", "launches_extend", "launches_shade", "launches_shadow"):
         assert st0[k] == st1[k]
+
+
+@pytest.mark.parametrize("n_threads", [3, 8])
+def test_n_threads_n_contexts_assemble_the_single_context_frame(n_threads):
+    """pbrs_amd/threads.py, the in-process driver INTEGRATION.md §2 describes for a Rust host (one context per device, one host
+    thread each, interleaved 8-row bands, one frame buffer): N contexts — here all on device 0, on a node one per GPU — render
+    one C3 frame together and the frame equals a single context's bit for bit, for a thread count that divides the bands
+    unevenly (3) and for the node's eight.  The report carries what a scaling run needs to explain itself: rows and bands per
+    thread and the band imbalance."""
+    from pbrs_amd import threads
+    sb, c = scenes.build_config("c3", width=192, height=136)  # 17 bands of 8 rows: 8 threads get 3 / 2 bands, 3 threads 6 / 6 / 5
+    hs = pbrs_amd.HostScene(sb)
+    one = pbrs_amd.Context(0)
+    one.upload(hs)
+    whole, _ = one.render(3, 3, c["depth"], 11)
+    one.close()
+    tf = threads.ThreadedFrame(hs, [0] * n_threads)
+    try:
+        for _ in range(2):  # consecutive frames through the same contexts
+            frame, rep = tf.render(3, 3, c["depth"], 11)
+            assert (bits(frame) == bits(whole)).all()
+    finally:
+        tf.close()
+    rows = [t["rows"] for t in rep["threads"]]
+    assert sum(rows) == 136 and len(rows) == n_threads
+    assert max(t["bands"] for t in rep["threads"]) - min(t["bands"] for t in rep["threads"]) <= 1
+    assert abs(rep["band_imbalance"] - max(rows) / (136 / n_threads)) < 1e-9
+    assert all(t["gpu_ms"] > 0 for t in rep["threads"])

@@ -64,9 +64,31 @@ def test_vector_issue_share_from_the_sq_pass():
     rep = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30, traffic_doc=doc)
     e = rep["extend"]
     assert e["valu_insts_per_launch"] == 1.2e6 and e["valu_lanes_active"] == 40.0
-    assert e["valu_issue_frac"] == 1.2e6 * 4 / (1024 * 1.0e-3 * 2.4e9)  # 2.0 ms over 2 launches
-    assert abs(e["valu_issue_frac_min"] - e["valu_issue_frac"] * 2.7 / 4) < 1e-12  # ... at the cheapest measured issue cost
+    assert e["valu_issue_frac_nominal"] == 1.2e6 * 4 / (1024 * 1.0e-3 * 2.4e9)  # 2.0 ms over 2 launches
+    assert abs(e["valu_issue_frac_min"] - e["valu_issue_frac_nominal"] * 2.7 / 4) < 1e-12  # ... at the cheapest measured issue cost
+    # no static mix for these sources: the midpoint of the two prices, and the share of 32-bit encodings is reported as unknown
+    assert e["valu_32bit_encoding_share"] is None and abs(e["valu_issue_frac"] - 1.2e6 * 3.35 / (1024 * 1.0e-3 * 2.4e9)) < 1e-12
     assert "valu_issue_frac" not in rep["shade"] and "valu_issue_frac" not in rep["shadow"]  # no SQ figures: not reported
+
+
+def test_calibrated_issue_share_from_the_static_encoding_mix_and_the_scalar_share():
+    """Round 4: the dynamic instruction count at the kernel's static mix of encodings (tools/isa_stats.py --json), capped at 1, is the
+    figure the bound is chosen with; scalar instructions are a share of their own; every share of bound_shares is <= 1."""
+    doc = {"source_hash": "abc", "geometry": {"frames": 1},
+           "kernels": {"k_extend<false, 13u>": {"launches": 2, "l2_fabric_total": 4.0e6, "valu_insts": 6.0e8, "valu_lanes_active": 37.0, "salu_insts": 2.0e8,
+                                                "l1_accesses": 5.0e8, "td_busy_share": 0.96}}}
+    isa = {"source_hash": "abc", "kernels": {"k_extend<false, 13u>": {"valu": 1000, "valu32": 600, "salu": 500}}}
+    e = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30, traffic_doc=doc, isa_doc=isa)["extend"]
+    slots = 1024 * 1.0e-3 * 2.4e9
+    assert e["valu_32bit_encoding_share"] == 0.6
+    assert abs(e["valu_issue_frac"] - 6.0e8 * (0.6 * 2.7 + 0.4 * 4.0) / slots) < 1e-12 and e["valu_issue_frac"] < 1.0 <= e["valu_issue_frac_nominal"] * 1.03
+    assert abs(e["salu_issue_frac"] - 2.0e8 * 4.25 / slots) < 1e-12
+    shares = roofline.bound_shares(e)
+    assert set(shares) == {"hbm", "valu_issue", "salu_issue", "l1_access", "td_busy"} and all(0.0 <= v <= 1.0 for v in shares.values())
+    assert roofline.bound_of(e) == "td_busy"
+    # an ISA document of other sources does not apply
+    other = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30, traffic_doc=doc, isa_doc=dict(isa, source_hash="xyz"))["extend"]
+    assert other["valu_32bit_encoding_share"] is None
 
 
 def test_measured_fraction_bound_and_the_new_key_names():

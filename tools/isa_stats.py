@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Developer tool: static instruction mix and register use per kernel, from the device assembly of pbrs_gpu.hip.
 
-    python tools/isa_stats.py [extra hipcc flags ...]     (CPU only; hipcc cross-compiles gfx950)
+    python tools/isa_stats.py [--json PATH] [extra hipcc flags ...]     (CPU only; hipcc cross-compiles gfx950)
+
+--json PATH also writes, per kernel, the static instruction mix bench.py prices the vector issue share with (pbrs_amd/roofline.py):
+vector instructions in all, those in a 32-bit encoding (`_e32`: VOP1 / VOP2 / VOPC forms without a literal — 2.7 issue cycles per
+wave on gfx950, tools/microbench/issue_rates.hip; the 64-bit encodings, DPP / SDWA forms and instructions with a 32-bit literal
+take about 4) and scalar instructions, stamped with the hash of the sources (profiles/latest_isa_mix.json).
 
 Prints, per kernel: VGPRs, SGPRs, scratch bytes, waves per SIMD, and the static counts of the instruction families that
 matter for the VALU-bound stages (correctly rounded f32 division = v_div_scale x2 + v_rcp + v_div_fmas + v_div_fixup,
@@ -22,7 +27,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
 
 FAMILIES = [
     ("div", r"v_div_fixup_f32"), ("rcp", r"v_rcp_f32"), ("sqrt", r"v_sqrt_f32"), ("rsq", r"v_rsq_f32"), ("f64", r"v_\w+_f64"),
-    ("cvt64", r"v_cvt_f(64_f32|32_f64)"), ("fma", r"v_fma_f32|v_fmac_f32"), ("cndmask", r"v_cndmask"), ("valu", r"^v_"), ("salu", r"^s_(?!waitcnt|nop|endpgm|branch|cbranch|barrier)"),
+    ("cvt64", r"v_cvt_f(64_f32|32_f64)"), ("fma", r"v_fma_f32|v_fmac_f32"), ("cndmask", r"v_cndmask"), ("valu", r"^v_"), ("valu32", r"^v_\w+_e32$"), ("salu", r"^s_(?!waitcnt|nop|endpgm|branch|cbranch|barrier)"),
     ("branch", r"^s_c?branch"), ("waitcnt", r"^s_waitcnt"), ("vmem_ld", r"^(global|buffer|flat)_load"), ("vmem_st", r"^(global|buffer|flat)_store"),
     ("atomic", r"^(global|buffer|flat)_atomic"), ("scratch", r"^scratch_"), ("lds", r"^ds_"), ("bpermute", r"ds_b?permute"),
 ]
@@ -34,9 +39,15 @@ def demangle(names):
 
 
 def main():
+    argv = sys.argv[1:]
+    json_path = None
+    if "--json" in argv:
+        k = argv.index("--json")
+        json_path = argv[k + 1]
+        del argv[k:k + 2]
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "dev.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + sys.argv[1:] + ["-o", asm, SRC], cwd=os.path.dirname(SRC))
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + argv + ["-o", asm, SRC], cwd=os.path.dirname(SRC))
         text = open(asm).read()
     kernels = {}
     cur = None
@@ -60,6 +71,8 @@ def main():
         kernels[cur]["insts"] += 1
         for fam, pat in FAMILIES:
             if re.search(pat, op):
+                if fam == "valu32" and re.search(r"\b0x[0-9a-f]+\b", s):
+                    continue  # a 32-bit literal follows the instruction word: 64 bits in all
                 kernels[cur][fam] += 1
     names = demangle(list(kernels))
     cols = ["insts"] + [f for f, _ in FAMILIES]
@@ -70,6 +83,17 @@ def main():
         n = names[k].split("(")[0].replace("void ", "")
         print("%-44s %5d %5d %7d %4d | " % (n[:44], c["@NumVgprs"], c.get("@TotalNumSgprs", c["@NumSgprs"]), c["@ScratchSize"], c["@Occupancy"]) +
               " ".join("%7d" % c[f] for f in cols))
+    if json_path:
+        import json
+        sys.path.insert(0, ROOT)
+        from pbrs_amd import roofline
+        doc = {"source_hash": roofline.source_hash(), "flags": " ".join(FLAGS + argv),
+               "note": "static counts per kernel: valu = vector instructions, valu32 = those in a 32-bit encoding (no literal), salu = scalar instructions",
+               "kernels": {names[k].split("(")[0].replace("void ", ""): {"valu": c["valu"], "valu32": c["valu32"], "salu": c["salu"], "vgpr": c["@NumVgprs"],
+                                                                          "scratch": c["@ScratchSize"], "waves_per_simd": c["@Occupancy"]}
+                           for k, c in kernels.items() if "@NumVgprs" in c}}
+        with open(json_path, "w") as f:
+            json.dump(doc, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -1,19 +1,35 @@
-"""Developer tool (GPU box): the two randomised-scene parity tests of tests/test_gpu_fuzz.py over a range of seeds far
-beyond the ones the suite runs: images of both integrators (also with two objects re-covered by Fourier BSDFs) and hit
-records / occlusion ray by ray, GPU vs oracle, bit for bit.
-usage: python tools/soak_fuzz.py [first_seed [end_seed]]   (default 48 3000; about 40 seeds per second)"""
-import os, sys
+"""Developer tool (GPU box): the randomised-scene parity tests of tests/test_gpu_fuzz.py over a range of seeds far beyond the ones
+the suite runs: images of both integrators (also with two objects re-covered by Fourier BSDFs) and hit records / occlusion ray by
+ray, GPU vs oracle, bit for bit.
+
+usage: python tools/soak_fuzz.py [first_seed [end_seed]] [--budget SECONDS]     (default 48 3000; about 40 seeds per second)
+
+The run ends ITSELF: at end_seed or when the wall-clock budget is spent (default 240 s), whichever comes first, and always prints
+its verdict line `seeds a .. b failures: [...]` and exits 0 (no failure) or 1 — size the budget to the GPU minutes at hand instead of
+letting the run's time limit cut it short without a verdict."""
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import pbrs_amd
-import test_gpu_fuzz as F
+import pbrs_amd  # noqa: E402
+import test_gpu_fuzz as F  # noqa: E402
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 48
-end = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+args = [a for a in sys.argv[1:]]
+budget = 240.0
+if "--budget" in args:
+    k = args.index("--budget")
+    budget = float(args[k + 1])
+    del args[k:k + 2]
+first = int(args[0]) if len(args) > 0 else 48
+end = int(args[1]) if len(args) > 1 else 3000
+t0 = time.perf_counter()
 ctx = pbrs_amd.Context(0)
 bad = []
-for seed in range(first, end):
+seed = first
+while seed < end and time.perf_counter() - t0 < budget:
     try:
         F.test_random_scene_rays_match_oracle(ctx, seed)
         F.test_random_scene_matches_oracle(ctx, seed)
@@ -21,6 +37,9 @@ for seed in range(first, end):
     except AssertionError as e:
         bad.append((seed, str(e)[:100]))
     if seed % 256 == 0:
-        print("seed", seed, "failures so far", len(bad), flush=True)
-print("seeds", first, "..", end - 1, "failures:", bad)
+        print("seed", seed, "failures so far", len(bad), "elapsed %.0f s" % (time.perf_counter() - t0), flush=True)
+    seed += 1
+print("seeds", first, "..", seed - 1, "failures:", bad, "(%.0f s of a %.0f s budget, library sources %s)" % (
+    time.perf_counter() - t0, budget, __import__("pbrs_amd.roofline", fromlist=["source_hash"]).source_hash()), flush=True)
+ctx.close()
 sys.exit(1 if bad else 0)

@@ -1,6 +1,6 @@
 """Turns rocprofv3 TCC counter passes (tools/pmc_summary.py outputs) into memory-side (L2 -> fabric) traffic per launch per kernel.
 
-    python tools/traffic_from_pmc.py GEOMETRY.json fetch.txt write.txt [rdreq_sizes.txt [wrreq.txt [sq_wave_cycles.txt [tcp.txt [ta_td.txt]]]]]
+    python tools/traffic_from_pmc.py GEOMETRY.json fetch.txt write.txt [rdreq_sizes.txt [wrreq.txt [sq_wave_cycles.txt [tcp.txt [ta_td.txt [sq_waves.txt]]]]]]
 
 Units and gfx950 corrections as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are in
 KiB and come from the L2's memory-side request counters (Infinity-Cache hits are counted, not excluded); on gfx950
@@ -40,6 +40,7 @@ wr = parse(sys.argv[5]) if len(sys.argv) > 5 else {}
 sq = parse(sys.argv[6]) if len(sys.argv) > 6 else {}
 tcp = parse(sys.argv[7]) if len(sys.argv) > 7 else {}
 tatd = parse(sys.argv[8]) if len(sys.argv) > 8 else {}
+sq2 = parse(sys.argv[9]) if len(sys.argv) > 9 else {}  # the second SQ pass: scalar, memory and LDS instruction counts
 n_pixels = geo["pixels"]
 n_slots = n_pixels * geo["samples_per_pass"]
 res = {"unit": "bytes per launch", "geometry": geo, "source_hash": geo.get("source_hash"), "git_head": geo.get("git_head"),
@@ -75,6 +76,11 @@ for k in fetch:
         row["valu_lanes_active"] = q.get("SQ_THREAD_CYCLES_VALU", 0.0) / q["SQ_INSTS_VALU"]  # of 64
         if q.get("SQ_WAVE_CYCLES"):
             row["wave_wait_share"] = q.get("SQ_WAIT_INST_ANY", 0.0) / q["SQ_WAVE_CYCLES"]  # of a wave's cycles spent waiting on an instruction's operands
+    if k in sq2 and sq2[k].get("SQ_INSTS_SALU") is not None:
+        q, dq = sq2[k], sq2[k]["dispatches"]
+        row["salu_insts"] = q["SQ_INSTS_SALU"] / dq               # wave-level scalar instructions per launch
+        row["vmem_rd_insts"] = q.get("SQ_INSTS_VMEM_RD", 0.0) / dq  # wave-level vector memory reads per launch
+        row["lds_insts"] = q.get("SQ_INSTS_LDS", 0.0) / dq          # wave-level LDS instructions per launch
     if k in tcp and tcp[k].get("TCP_TOTAL_CACHE_ACCESSES_sum") is not None:
         q, dq = tcp[k], tcp[k]["dispatches"]
         row["l1_accesses"] = q["TCP_TOTAL_CACHE_ACCESSES_sum"] / dq           # per launch, summed over the CUs
