@@ -506,12 +506,56 @@ PD float power_heuristic2(float f_pdf, float g_pdf) {  // src/directlighting.rs:
 //   PBRS_SHADE_FOURIER_ONLY   (with PBRS_SHADE_FOURIER) every vertex the launch meets is on a Fourier material, whose one lobe is the
 //                             Fourier BSDF: the launch over that class of a class-major queue (pbrs_gpu.hip)
 #define PBRS_SHADE_FOURIER_ONLY 16u
+//   PBRS_SHADE_LDS_RECORDS    the scene's instance records, analytic shapes, materials, lobes and lights are copied into the block's LDS
+//   PBRS_SHADE_LDS_TRIS       ... and its triangle vertex and shading records (scenes of a few KB)
+// at kernel start (stage_shade_scene): a vertex's ~25 record fetches — the instance's two matrices, the triangle's seven vectors, material,
+// lobe and light — are gathers that cost the CU's texture path a cycle or two per lane each (k_shade's texture data unit was 0.93-0.95
+// busy on C2 / C3) and the LDS a third of that, at a third of the latency (tools/microbench/gather_lds_coop.hip).  Chosen per scene by what fits
+// (pbrs_upload_scene): C2 / C3 both, C4 (a million triangles, six instances) the records.
+#define PBRS_SHADE_LDS_RECORDS 32u
+#define PBRS_SHADE_LDS_TRIS 64u
 #ifndef PBRS_FOURIER_AK_ROWS
 #define PBRS_FOURIER_AK_ROWS 48u  // terms of a luminance series kept in LDS per lane; longer series are recomputed where they are consumed
 #endif
+PD uint4* stage_array(uint4* dst, const void* src_, uint32_t n16) {
+    const uint4* src = reinterpret_cast<const uint4*>(src_);
+    for (uint32_t i = threadIdx.x; i < n16; i += 256u) dst[i] = src[i];
+    return dst + n16;
+}
+template <uint32_t SPEC>
+PD DevScene stage_shade_scene(const DevScene& G, uint32_t* lds_base) {
+    DevScene S = G;
+    uint4* dst = reinterpret_cast<uint4*>(__builtin_assume_aligned(lds_base, 16));
+    if (SPEC & PBRS_SHADE_LDS_RECORDS) {
+        S.inst = reinterpret_cast<const pbrs_instance*>(dst);
+        dst = stage_array(dst, G.inst, G.n_inst * (uint32_t)(sizeof(pbrs_instance) / 16));
+        S.shapes = reinterpret_cast<const pbrs_shape*>(dst);
+        dst = stage_array(dst, G.shapes, G.n_shapes * (uint32_t)(sizeof(pbrs_shape) / 16));
+        S.mats = reinterpret_cast<const pbrs_material*>(dst);
+        dst = stage_array(dst, G.mats, G.n_mats * (uint32_t)(sizeof(pbrs_material) / 16));
+        S.bxdfs = reinterpret_cast<const pbrs_bxdf*>(dst);
+        dst = stage_array(dst, G.bxdfs, G.n_bxdfs * (uint32_t)(sizeof(pbrs_bxdf) / 16));
+        S.alights = reinterpret_cast<const pbrs_area_light*>(dst);
+        dst = stage_array(dst, G.alights, G.n_area * (uint32_t)(sizeof(pbrs_area_light) / 16));
+        S.dlights = reinterpret_cast<const pbrs_delta_light*>(dst);
+        dst = stage_array(dst, G.dlights, G.n_delta * (uint32_t)(sizeof(pbrs_delta_light) / 16));
+    }
+    if (SPEC & PBRS_SHADE_LDS_TRIS) {
+        S.tv = reinterpret_cast<const pbrs_tri_verts*>(dst);
+        dst = stage_array(dst, G.tv, G.n_tris * (uint32_t)(sizeof(pbrs_tri_verts) / 16));
+        S.ts = reinterpret_cast<const pbrs_tri_shade*>(dst);
+        dst = stage_array(dst, G.ts, G.n_tris * (uint32_t)(sizeof(pbrs_tri_shade) / 16));
+    }
+    __syncthreads();
+    return S;
+}
+static_assert(sizeof(pbrs_material) % 16 == 0 && sizeof(pbrs_bxdf) % 16 == 0 && sizeof(pbrs_area_light) % 16 == 0 && sizeof(pbrs_delta_light) % 16 == 0 &&
+                  sizeof(pbrs_tri_shade) % 16 == 0,
+              "stage_shade_scene copies 16-byte pieces");
 template <uint32_t INTEG, bool TEX, uint32_t SPEC>
-__global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : PBRS_SHADE_WAVES) k_shade(DevScene S, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
+__global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : PBRS_SHADE_WAVES) k_shade(DevScene G, PathState st, RenderConst rc, uint32_t bounce, const uint32_t* count, uint32_t n_direct,
                                               uint32_t* count_out, uint32_t* nee_queue, unsigned long long* nee_shadow_count, uint32_t sorted, const uint2* range) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_shade_scene[];
     // per-hit lobe lists of textured materials (Bsdf::hit_lobe / hit_albedo); absent from the untextured instantiation
     __shared__ uint32_t s_hit_lobe[TEX ? PBRS_MAX_BXDFS * 256 : 1];
     __shared__ float s_hit_albedo[TEX ? 3 * PBRS_MAX_BXDFS * 256 : 1];
@@ -529,7 +573,10 @@ __global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : 
         i += r.x;
         n = r.y;
         if (blockIdx.x * blockDim.x + r.x >= n) return;  // the grid is sized for the whole queue
+    } else if (blockIdx.x * blockDim.x >= n) {
+        return;  // ... of the pass: a block beyond the bounce's queue has nothing to shade, nothing to compact
     }
+    const DevScene S = (SPEC & (PBRS_SHADE_LDS_RECORDS | PBRS_SHADE_LDS_TRIS)) ? stage_shade_scene<SPEC>(G, lds_shade_scene) : G;
     bool valid = i < n;
     bool alive = false, cast0 = false, cast1 = false;
     uint32_t slot = 0;

@@ -59,6 +59,8 @@ struct DevScene {
     // shape — is copied into each block's LDS behind its stack rows at kernel start (PBRS_FEAT_LDS_SCENE kernels; kernels.h,
     // stage_scene): element counts, and the word offset of the copy in the block's dynamic LDS (a multiple of 4).  0 nodes: not staged.
     uint32_t lds_off_words, lds_nodes, lds_tris, lds_inst, lds_shapes;
+    // element counts of the arrays k_shade may stage in LDS (kernels.h, stage_shade_scene); n_area / n_delta above
+    uint32_t n_inst, n_shapes, n_tris, n_mats, n_bxdfs;
 };
 
 // Scene features the traversal kernels are specialised on (pbrs_upload_scene derives them from the arrays it checks).

@@ -97,6 +97,8 @@ struct pbrs_ctx {
     bool full_steps = false;       // ... whose further node steps are full ones (PBRS_FEAT_FULL_STEPS): what the walks read exceeds the last-level cache
     uint64_t cache_bytes = 256ull << 20;  // the last-level cache the per-scene choices assume (MI355X: 256 MiB Infinity Cache); pbrs_set_cache_bytes
     uint64_t walk_bytes = 0;       // bytes of the arrays the walks read (nodes, wide nodes, triangle vertices, instances)
+    uint32_t shade_lds = 0;        // PBRS_SHADE_LDS_*: what k_shade<PATH>'s untextured variants stage in LDS for this scene (kernels.h)
+    size_t shade_lds_bytes = 0;
     bool lds_scene = false;        // ... and they fit next to a block's stack rows: the PBRS_FEAT_LDS_SCENE kernels (S.lds_*)
     size_t lds_scene_bytes = 0;
     bool shadow_flat = false;      // k_shadow scans the TLAS leaves (up to PBRS_FLAT_TLAS_MAX_ANYHIT instances; k_extend: S.features)
@@ -556,9 +558,20 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
             hipLaunchKernelGGL(k_class_sort, dim3(n_tiles), dim3(kBlock), 0, c->stream, c->st, cnt_in, N);
         }
         {
-#define PBRS_LAUNCH_SHADE(I, T, SP)                                                                                                       \
-    hipLaunchKernelGGL((k_shade<I, T, SP>), dim3(shade_grid), dim3(kBlock), 0, c->stream, c->S, c->st, rc, b, shade_count, N, act + b + 1, neeq, ns + b, \
+#define PBRS_LAUNCH_SHADE_LDS(I, T, SP, LDS)                                                                                              \
+    hipLaunchKernelGGL((k_shade<I, T, SP>), dim3(shade_grid), dim3(kBlock), LDS, c->stream, c->S, c->st, rc, b, shade_count, N, act + b + 1, neeq, ns + b, \
                        sorted | split_sorted, shade_range)
+#define PBRS_LAUNCH_SHADE(I, T, SP) PBRS_LAUNCH_SHADE_LDS(I, T, SP, 0)
+// the path integrator's untextured variants: with the scene's shading records (and triangle records) staged in LDS where they fit
+#define PBRS_LAUNCH_SHADE_PATH(SP)                                                                                                               \
+    do {                                                                                                                                          \
+        if (c->shade_lds == (PBRS_SHADE_LDS_RECORDS | PBRS_SHADE_LDS_TRIS))                                                                        \
+            PBRS_LAUNCH_SHADE_LDS(PBRS_INTEGRATOR_PATH, false, (SP) | PBRS_SHADE_LDS_RECORDS | PBRS_SHADE_LDS_TRIS, c->shade_lds_bytes);           \
+        else if (c->shade_lds == PBRS_SHADE_LDS_RECORDS)                                                                                           \
+            PBRS_LAUNCH_SHADE_LDS(PBRS_INTEGRATOR_PATH, false, (SP) | PBRS_SHADE_LDS_RECORDS, c->shade_lds_bytes);                                 \
+        else                                                                                                                                       \
+            PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, SP);                                                                                    \
+    } while (0)
             const uint32_t shade_grid = grid;
             const uint2* shade_range = qsplit ? c->st.class_range + 1 : nullptr;  // a split queue: the kept paths
             const uint32_t split_sorted = qsplit ? 1u : 0u;
@@ -595,26 +608,24 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
             } else if (split) {
                 shade_range = c->st.class_range + c->lambert_class;
                 switch (c->light_spec) {
-                    case PBRS_SHADE_LIGHT_SPHERE: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_SPHERE); break;
-                    case PBRS_SHADE_LIGHT_TRIANGLE: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_TRIANGLE); break;
-                    default: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT); break;
+                    case PBRS_SHADE_LIGHT_SPHERE: PBRS_LAUNCH_SHADE_PATH(PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_SPHERE); break;
+                    case PBRS_SHADE_LIGHT_TRIANGLE: PBRS_LAUNCH_SHADE_PATH(PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_TRIANGLE); break;
+                    default: PBRS_LAUNCH_SHADE_PATH(PBRS_SHADE_LAMBERT); break;
                 }
                 shade_range = c->st.class_range + PBRS_MAX_CLASSES;
-                PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, 0u);
+                PBRS_LAUNCH_SHADE_PATH(0u);
             } else {  // the path integrator, specialised on what the scene's materials and lights are (c->shade_spec)
                 switch (c->shade_spec) {
-                    case PBRS_SHADE_LAMBERT: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT); break;
-                    case PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_SPHERE:
-                        PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_SPHERE);
-                        break;
-                    case PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_TRIANGLE:
-                        PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_TRIANGLE);
-                        break;
-                    default: PBRS_LAUNCH_SHADE(PBRS_INTEGRATOR_PATH, false, 0u); break;
+                    case PBRS_SHADE_LAMBERT: PBRS_LAUNCH_SHADE_PATH(PBRS_SHADE_LAMBERT); break;
+                    case PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_SPHERE: PBRS_LAUNCH_SHADE_PATH(PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_SPHERE); break;
+                    case PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_TRIANGLE: PBRS_LAUNCH_SHADE_PATH(PBRS_SHADE_LAMBERT | PBRS_SHADE_LIGHT_TRIANGLE); break;
+                    default: PBRS_LAUNCH_SHADE_PATH(0u); break;
                 }
             }
             }
+#undef PBRS_LAUNCH_SHADE_PATH
 #undef PBRS_LAUNCH_SHADE
+#undef PBRS_LAUNCH_SHADE_LDS
         }
         tm.end();
         if (tm.begin(3)) return fail(c, PBRS_E_DEVICE, "event record failed");
@@ -1187,6 +1198,18 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         S.lds_tris = c->lds_scene ? d->n_triangles : 0u;
         S.lds_inst = c->lds_scene ? d->n_instances : 0u;
         S.lds_shapes = c->lds_scene ? d->n_shapes : 0u;
+    }
+    // k_shade: the shading records (instances, shapes, materials, lobes, lights) in LDS where they are a few KB, the triangle records
+    // too where everything is (kernels.h, stage_shade_scene); five blocks of the Lambert variants share a CU's 160 KB with the rest
+    {
+        S.n_inst = d->n_instances; S.n_shapes = d->n_shapes; S.n_tris = d->n_triangles; S.n_mats = d->n_materials; S.n_bxdfs = d->n_bxdfs;
+        const size_t rec = (size_t)d->n_instances * sizeof(pbrs_instance) + (size_t)d->n_shapes * sizeof(pbrs_shape) + (size_t)d->n_materials * sizeof(pbrs_material) +
+                           (size_t)d->n_bxdfs * sizeof(pbrs_bxdf) + (size_t)d->n_area_lights * sizeof(pbrs_area_light) + (size_t)d->n_delta_lights * sizeof(pbrs_delta_light);
+        const size_t tris = (size_t)d->n_triangles * (sizeof(pbrs_tri_verts) + sizeof(pbrs_tri_shade));
+        const size_t budget = 16u << 10;
+        c->shade_lds = rec + tris <= budget ? (PBRS_SHADE_LDS_RECORDS | PBRS_SHADE_LDS_TRIS) : rec <= budget ? PBRS_SHADE_LDS_RECORDS : 0u;
+        if (const char* e = dev_env("PBRS_SHADE_LDS")) c->shade_lds &= (uint32_t)std::atoi(e);  // developer override (A/B timing): a mask
+        c->shade_lds_bytes = (c->shade_lds & PBRS_SHADE_LDS_TRIS) ? rec + tris : c->shade_lds ? rec : 0;
     }
     c->S = S;
     c->textured = textured;
