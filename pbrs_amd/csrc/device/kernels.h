@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : 
 #ifdef PBRS_PROBE_SHADE
     PBRS_SHADE_MARK(7);  // compaction + queue / record writes
     if ((threadIdx.x & 63u) == 0 && __ballot(valid) != 0 && (blockIdx.x % 61u) == 0)  // a sample of the blocks
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_shade_probe[k], probe_acc[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_shade_probe[((SPEC & PBRS_SHADE_LAMBERT) ? 0 : 8) + k], probe_acc[k]);  // [0..7] the Lambert variants, [8..15] the others
 #endif
 }
 

@@ -17,7 +17,10 @@ img, st = ctx.render(4, 4, cfg["depth"], 1, timing=True)
 L.pbrs_debug_shade_probe(buf)
 names = ["loads+emission", "interaction rebuild + frame", "NEE light sample + pdf", "NEE term1 eval/pdf/MIS", "NEE term2 sample+light isect",
          "NEE bookkeeping", "bounce sample/RR/stores", "compaction + writes"]
-tot = sum(buf[:8])
-print(name, "ms_shade %.3f" % st["ms_shade"], "total wave-cycles %.3e" % tot)
-for k, n in enumerate(names):
-    print("  %-32s %5.1f %%" % (n, 100.0 * buf[k] / tot))
+for off, what in ((0, "the Lambert variants"), (8, "the general / textured / Fourier variants")):
+    tot = sum(buf[off:off + 8])
+    if not tot:
+        continue
+    print(name, what, "ms_shade (all variants) %.3f" % st["ms_shade"], "wave-cycles of the sampled blocks %.3e" % tot)
+    for k, n in enumerate(names):
+        print("  %-32s %5.1f %%" % (n, 100.0 * buf[off + k] / tot))
