@@ -346,7 +346,7 @@ struct ClosestSel {
 };
 template <bool STATS, uint32_t FEAT>
 struct ClosestSel<0u, STATS, FEAT> {
-    typedef ClosestWalk<STATS, (FEAT & PBRS_FEAT_ALL)> type;
+    typedef ClosestWalk<STATS, (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_LDS_TOP))> type;
 };
 template <uint32_t ARITY, bool STATS, uint32_t FEAT>
 struct AnySel {
@@ -354,7 +354,7 @@ struct AnySel {
 };
 template <bool STATS, uint32_t FEAT>
 struct AnySel<0u, STATS, FEAT> {
-    typedef AnyWalk<STATS, (FEAT & PBRS_FEAT_ALL)> type;
+    typedef AnyWalk<STATS, (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_LDS_TOP))> type;
 };
 #define PBRS_WALK_ARITY(STATS, FEAT) ((STATS) ? 0u : ((FEAT) & PBRS_FEAT_WIDE) ? 4u : 0u)
 #ifndef PBRS_NODE_STEPS_SHORT  // node steps per round in scenes with short walks: one (two, the second a lean one: C2 -2.3 %, C3 -3.2 %)
@@ -393,6 +393,19 @@ PD DevScene stage_scene(const DevScene& G, uint32_t* lds_base) {
 }
 static_assert(sizeof(pbrs_node) % 16 == 0 && sizeof(pbrs_tri_verts) % 16 == 0 && sizeof(pbrs_instance) % 16 == 0 && sizeof(pbrs_shape) % 16 == 0, "stage_scene copies 16-byte pieces");
 
+// PBRS_FEAT_LDS_TOP: scenes whose arrays do not fit as a whole but whose TLAS does (C5: 130 instances, 259 nodes, 8 KB) get the head of the
+// node array staged — a ray of such a scene tests some thirty TLAS boxes, five of a BLAS.
+PD DevScene stage_top(const DevScene& G, uint32_t* lds_base) {
+    DevScene S = G;
+    uint4* dst = reinterpret_cast<uint4*>(__builtin_assume_aligned(lds_base + G.lds_off_words, 16));
+    const uint4* src = reinterpret_cast<const uint4*>(G.nodes);
+    const uint32_t n16 = G.lds_nodes * (uint32_t)(sizeof(pbrs_node) / 16);
+    for (uint32_t i = threadIdx.x; i < n16; i += PBRS_TRAVERSAL_BLOCK) dst[i] = src[i];
+    S.nodes_top = reinterpret_cast<const pbrs_node*>(dst);
+    __syncthreads();
+    return S;
+}
+
 // Persistent: every wave keeps pulling rays from the queue until it is empty; a lane whose walk ends is
 // handed a new ray at the next refill, the walks of the other lanes continue where they were.
 // `indirect` (binary-walk kernels working off a slow list): the queue positions to trace, `count` of them.
@@ -401,7 +414,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
     k_extend(DevScene G, PathState st, uint32_t set, const uint32_t* count, uint32_t n_direct, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect,
              uint32_t* slow_list, uint32_t* slow_count, uint32_t split) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    const DevScene S = (!STATS && (FEAT & PBRS_FEAT_LDS_SCENE)) ? stage_scene(G, lds_stack) : G;
+    const DevScene S = (!STATS && (FEAT & PBRS_FEAT_LDS_SCENE)) ? stage_scene(G, lds_stack) : (!STATS && (FEAT & PBRS_FEAT_LDS_TOP)) ? stage_top(G, lds_stack) : G;
     constexpr uint32_t ARITY = PBRS_WALK_ARITY(STATS, FEAT);
     constexpr bool WIDE = ARITY != 0u;
     const uint32_t n = count ? *count : n_direct;
@@ -411,7 +424,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
-    typename ClosestSel<ARITY, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
+    typename ClosestSel<ARITY, STATS, (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_LDS_TOP))>::type walk;
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
     PBRS_TT_DECL;
@@ -1143,7 +1156,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
     k_shadow(DevScene G, PathState st, const uint32_t* count, uint32_t* next, GlobalCounters* gc, const uint32_t* indirect, uint32_t* slow_list,
              uint32_t* slow_count) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    const DevScene S = (!STATS && (FEAT & PBRS_FEAT_LDS_SCENE)) ? stage_scene(G, lds_stack) : G;
+    const DevScene S = (!STATS && (FEAT & PBRS_FEAT_LDS_SCENE)) ? stage_scene(G, lds_stack) : (!STATS && (FEAT & PBRS_FEAT_LDS_TOP)) ? stage_top(G, lds_stack) : G;
     constexpr uint32_t ARITY = PBRS_WALK_ARITY(STATS, FEAT);
     constexpr bool WIDE = ARITY != 0u;
     const uint32_t n = indirect ? count[0] : count[1];  // a slow list's length, or the high half of the packed (nee paths, shadow rays) counter
@@ -1151,7 +1164,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0;
-    typename AnySel<ARITY, STATS, (FEAT & PBRS_FEAT_ALL)>::type walk;
+    typename AnySel<ARITY, STATS, (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_LDS_TOP))>::type walk;
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
     PBRS_TT_DECL;

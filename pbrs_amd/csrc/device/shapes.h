@@ -59,6 +59,9 @@ struct DevScene {
     // shape — is copied into each block's LDS behind its stack rows at kernel start (PBRS_FEAT_LDS_SCENE kernels; kernels.h,
     // stage_scene): element counts, and the word offset of the copy in the block's dynamic LDS (a multiple of 4).  0 nodes: not staged.
     uint32_t lds_off_words, lds_nodes, lds_tris, lds_inst, lds_shapes;
+    // PBRS_FEAT_LDS_TOP kernels: only the first lds_nodes nodes (the TLAS) are staged, and read through this pointer (nullptr in the uploaded
+    // scene; the kernel points it at its block's copy): nodes[i] for i < lds_nodes comes from the LDS, every other node from DevScene::nodes
+    const pbrs_node* nodes_top;
     // element counts of the arrays k_shade may stage in LDS (kernels.h, stage_shade_scene); n_area / n_delta above
     uint32_t n_inst, n_shapes, n_tris, n_mats, n_bxdfs;
 };
@@ -75,6 +78,7 @@ struct DevScene {
 #define PBRS_FEAT_ALL 7u
 #define PBRS_FEAT_LONG_WALKS 8u     // kernels only (not a property of the walks): several node steps per loop round (kernels.h)
 #define PBRS_FEAT_WIDE 16u          // kernels only: the walks over four-wide nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
+#define PBRS_FEAT_LDS_TOP 128u      // kernels only: the head of DevScene::nodes — a TLAS too large to scan — is copied into the block's LDS (scenes whose arrays do not fit as a whole)
 #define PBRS_FEAT_LDS_SCENE 64u     // kernels only: the arrays the walks read are copied into the block's LDS at kernel start (scenes of a few KB; kernels.h)
 #define PBRS_FEAT_FULL_STEPS 32u    // kernels only (with PBRS_FEAT_LONG_WALKS): a round's further node steps are full steps (kernels.h): scenes beyond the last-level cache
 #define PBRS_FLAT_TLAS_MIN 2u
@@ -367,6 +371,17 @@ struct Hit {
 PD f3 nmin(const pbrs_node& n) { return mk3(n.min[0], n.min[1], n.min[2]); }
 PD f3 nmax(const pbrs_node& n) { return mk3(n.max[0], n.max[1], n.max[2]); }
 
+// ... from the block's LDS, through pointers that say so (left to infer it, the compiler merges an LDS path and a global path of the same
+// loads into flat loads behind a pointer select, which send every fetch through the texture path: measured on the wide nodes)
+#define PBRS_LDS_AS __attribute__((address_space(3)))
+typedef float pbrs_f4v __attribute__((ext_vector_type(4)));
+PD pbrs_node load_node_lds(const PBRS_LDS_AS char* p) {
+    const pbrs_f4v a = *reinterpret_cast<const PBRS_LDS_AS pbrs_f4v*>(p), b = *reinterpret_cast<const PBRS_LDS_AS pbrs_f4v*>(p + 16);
+    pbrs_node n;
+    n.min[0] = a.x; n.min[1] = a.y; n.min[2] = a.z; n.a = __float_as_uint(a.w);
+    n.max[0] = b.x; n.max[1] = b.y; n.max[2] = b.z; n.b = __float_as_uint(b.w);
+    return n;
+}
 // Loads one 32-byte node as two 16-byte vectors (coalescing unit of the LDS/HBM path on gfx950).
 PD pbrs_node load_node(const pbrs_node* p) {
     const float4* q = reinterpret_cast<const float4*>(p);
@@ -381,6 +396,14 @@ PD pbrs_node load_node(const pbrs_node* p) {
 PD pbrs_node load_node_at(const pbrs_node* base, uint32_t i) {
     const char* p = reinterpret_cast<const char*>(base) + (uint32_t)(i * (uint32_t)sizeof(pbrs_node));
     return load_node(reinterpret_cast<const pbrs_node*>(p));
+}
+// A walk's node fetch: in the PBRS_FEAT_LDS_TOP kernels the head of the node array (the TLAS) comes from the block's LDS
+template <uint32_t FEAT>
+PD pbrs_node walk_node(const DevScene& S, uint32_t i) {
+    if constexpr ((FEAT & PBRS_FEAT_LDS_TOP) != 0u) {
+        if (i < S.lds_nodes) return load_node_lds((const PBRS_LDS_AS char*)S.nodes_top + i * (uint32_t)sizeof(pbrs_node));
+    }
+    return load_node_at(S.nodes, i);
 }
 PD pbrs_tri_verts load_tri(const pbrs_tri_verts* p) {
     const float4* q = reinterpret_cast<const float4*>(p);

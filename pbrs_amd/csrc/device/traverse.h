@@ -455,7 +455,7 @@ struct ClosestWalk {
                 else CNT(tlas_nodes);
             }
         }
-        const pbrs_node node = load_node_at(S.nodes, ni);
+        const pbrs_node node = walk_node<FEAT>(S, ni);
         PBRS_TP(1);
         if (!slab_rs(node, C, lt)) {
             PBRS_TP(2);
@@ -497,7 +497,7 @@ struct ClosestWalk {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
         }
-        const pbrs_node node = load_node_at(S.nodes, ni);
+        const pbrs_node node = walk_node<FEAT>(S, ni);
         PBRS_TP(1);
         RaySpace F = C;
         F.fast = true;  // known here: this copy of the box test carries no division path
@@ -784,7 +784,7 @@ struct AnyWalk {
             return;
         }
         const uint32_t ni = stk.get(--sp);
-        const pbrs_node node = load_node_at(S.nodes, ni);
+        const pbrs_node node = walk_node<FEAT>(S, ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);
@@ -816,7 +816,7 @@ struct AnyWalk {
         if (sp == (in_blas ? blas_base : 0) || !C.fast) return;
         PBRS_TP(0);
         const uint32_t ni = stk.get(--sp);
-        const pbrs_node node = load_node_at(S.nodes, ni);
+        const pbrs_node node = walk_node<FEAT>(S, ni);
         if (STATS) {
             if (in_blas) CNT(blas_nodes);
             else CNT(tlas_nodes);

@@ -99,6 +99,8 @@ struct pbrs_ctx {
     uint64_t walk_bytes = 0;       // bytes of the arrays the walks read (nodes, wide nodes, triangle vertices, instances)
     uint32_t shade_lds = 0;        // PBRS_SHADE_LDS_*: what k_shade<PATH>'s untextured variants stage in LDS for this scene (kernels.h)
     size_t shade_lds_bytes = 0;
+    bool lds_top = false;          // ... or only the TLAS does (an unscanned one): the PBRS_FEAT_LDS_TOP kernels
+    size_t lds_top_bytes = 0;
     bool lds_scene = false;        // ... and they fit next to a block's stack rows: the PBRS_FEAT_LDS_SCENE kernels (S.lds_*)
     size_t lds_scene_bytes = 0;
     bool shadow_flat = false;      // k_shadow scans the TLAS leaves (up to PBRS_FLAT_TLAS_MAX_ANYHIT instances; k_extend: S.features)
@@ -388,10 +390,11 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
 // `slow_*`: see kernels.h.
 typedef void (*extend_fn_t)(DevScene, PathState, uint32_t, const uint32_t*, uint32_t, uint32_t*, GlobalCounters*, const uint32_t*, uint32_t*, uint32_t*, uint32_t);
 typedef void (*shadow_fn_t)(DevScene, PathState, const uint32_t*, uint32_t*, GlobalCounters*, const uint32_t*, uint32_t*, uint32_t*);
-constexpr uint32_t kFeatCombos = 128u;  // PBRS_FEAT_* bits 0 .. 6
+constexpr uint32_t kFeatCombos = 256u;  // PBRS_FEAT_* bits 0 .. 7
 constexpr bool extend_feat_ok(uint32_t f) {
     if ((f & PBRS_FEAT_FULL_STEPS) && !(f & PBRS_FEAT_LONG_WALKS)) return false;  // further node steps exist in the long-walk kernels only
     if ((f & PBRS_FEAT_LDS_SCENE) && (f & (PBRS_FEAT_WIDE | PBRS_FEAT_FULL_STEPS))) return false;  // a scene of a few KB
+    if ((f & PBRS_FEAT_LDS_TOP) && (f & (PBRS_FEAT_LDS_SCENE | PBRS_FEAT_WIDE | PBRS_FEAT_FULL_STEPS | PBRS_FEAT_FLAT_TLAS))) return false;  // a TLAS too large to scan
     if (f & PBRS_FEAT_WIDE) {
 #ifdef PBRS_DEV_OVERRIDES  // the four-wide closest-hit walk (device/experimental/closest_wide.h)
         return (f & PBRS_FEAT_FLAT_TLAS) && !(f & PBRS_FEAT_FULL_STEPS);
@@ -405,6 +408,7 @@ constexpr bool shadow_feat_ok(uint32_t f) {
     if (f & PBRS_FEAT_SHADING_CHECK) return false;
     if ((f & PBRS_FEAT_FULL_STEPS) && !(f & PBRS_FEAT_LONG_WALKS)) return false;
     if ((f & PBRS_FEAT_LDS_SCENE) && (f & (PBRS_FEAT_WIDE | PBRS_FEAT_FULL_STEPS))) return false;
+    if ((f & PBRS_FEAT_LDS_TOP) && (f & (PBRS_FEAT_LDS_SCENE | PBRS_FEAT_WIDE | PBRS_FEAT_FULL_STEPS | PBRS_FEAT_FLAT_TLAS))) return false;
     if ((f & PBRS_FEAT_WIDE) && !(f & PBRS_FEAT_FLAT_TLAS)) return false;
     return true;
 }
@@ -448,6 +452,9 @@ int launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds,
     if (c->lds_scene && !wide) {
         feat |= PBRS_FEAT_LDS_SCENE;
         lds += c->lds_scene_bytes;
+    } else if (c->lds_top && !wide && !(feat & (PBRS_FEAT_FLAT_TLAS | PBRS_FEAT_FULL_STEPS))) {
+        feat |= PBRS_FEAT_LDS_TOP;
+        lds += c->lds_top_bytes;
     }
     const extend_fn_t fn = extend_fns()[feat];
     if (!fn) return fail(c, PBRS_E_DEVICE, "no k_extend instantiation for this scene's feature set");
@@ -469,6 +476,9 @@ int launch_shadow(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds,
     if (c->lds_scene && !wide) {
         feat |= PBRS_FEAT_LDS_SCENE;
         lds += c->lds_scene_bytes;
+    } else if (c->lds_top && !wide && !(feat & (PBRS_FEAT_FLAT_TLAS | PBRS_FEAT_FULL_STEPS))) {
+        feat |= PBRS_FEAT_LDS_TOP;
+        lds += c->lds_top_bytes;
     }
     const shadow_fn_t fn = shadow_fns()[feat];
     if (!fn) return fail(c, PBRS_E_DEVICE, "no k_shadow instantiation for this scene's feature set");
@@ -1193,8 +1203,13 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
         c->lds_scene = !c->wide_shadow && !c->wide_extend && !c->full_steps && stack_bytes + scene_bytes <= kLdsBytesPerCU / 8;
         if (const char* e = dev_env("PBRS_LDS_SCENE")) c->lds_scene = c->lds_scene && std::atoi(e) != 0;  // developer override (A/B timing)
         c->lds_scene_bytes = c->lds_scene ? scene_bytes : 0;
+        // ... or the TLAS alone, where it is too large for the wave's shared scan (no leaf copies) and fits with seven blocks to a CU
+        const size_t top_bytes = (size_t)d->n_tlas_nodes * sizeof(pbrs_node);
+        c->lds_top = !c->lds_scene && S.n_flat == 0u && !c->full_steps && stack_bytes + top_bytes + 512 <= kLdsBytesPerCU / 7;
+        if (const char* e = dev_env("PBRS_LDS_TOP")) c->lds_top = c->lds_top && std::atoi(e) != 0;  // developer override (A/B timing)
+        c->lds_top_bytes = c->lds_top ? top_bytes : 0;
         S.lds_off_words = depth * kBlock;
-        S.lds_nodes = c->lds_scene ? (uint32_t)n_scene_nodes : 0u;
+        S.lds_nodes = c->lds_scene ? (uint32_t)n_scene_nodes : c->lds_top ? d->n_tlas_nodes : 0u;
         S.lds_tris = c->lds_scene ? d->n_triangles : 0u;
         S.lds_inst = c->lds_scene ? d->n_instances : 0u;
         S.lds_shapes = c->lds_scene ? d->n_shapes : 0u;
