@@ -163,7 +163,10 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 #define PBRS_REFILL_BELOW_SHORT 20u  // C2 extend 9.23 / 8.92 / 9.04 ms per 16 spp at 40 / 24 / 16
 #endif
 #ifndef PBRS_REFILL_BELOW_LONG
-#define PBRS_REFILL_BELOW_LONG 48u   // C4 extend 25.9 / 24.5 / 23.8 ms per 16 spp at 24 / 40 / 48
+#define PBRS_REFILL_BELOW_LONG 48u   // C4 extend 25.9 / 24.5 / 23.8 ms per 16 spp at 24 / 40 / 48; per frame 398.5 / 392.4 / 418.3 / 452.5 ms at 40 / 48 / 56 / 60 (round 4)
+#endif
+#ifndef PBRS_REFILL_BELOW_LONG_SHADOW
+#define PBRS_REFILL_BELOW_LONG_SHADOW 40u  // C4 shadow 205.3 / 209.9 / 231.5 ms per frame at 40 / 48 / 56 (profiles/r04j_ab_refill_thresholds_c4.log)
 #endif
 #define PBRS_LONG_WALK_HEIGHT 12u    // a mesh whose BLAS is at least this high makes the scene's walks "long"
 #ifndef PBRS_NODE_STEPS_LONG
@@ -1172,7 +1175,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
-        if ((uint32_t)__popcll(live) < S.refill_below) {
+        if ((uint32_t)__popcll(live) < S.refill_below_shadow) {
             PBRS_KP_WAVE(1);
             if constexpr (WIDE) {
                 wave_append_slow(walk.mode == PBRS_WALK_SLOW, rec, slow_list, slow_count);

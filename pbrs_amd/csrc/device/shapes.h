@@ -40,6 +40,7 @@ struct DevScene {
     uint32_t flat_off, n_flat;
     uint32_t features;   // PBRS_FEAT_*: what the traversal kernels must be able to do for this scene
     uint32_t refill_below;  // a wave of a traversal kernel takes new rays when fewer of its lanes than this are walking
+    uint32_t refill_below_shadow;  // ... of k_shadow (any-hit walks end at the first occluder: later, larger refills)
     // texture/src/lib.rs (device/textures.h) and the environment light (scene/src/lib.rs:105-117)
     const pbrs_texture* textures;
     const float* tex_floats;

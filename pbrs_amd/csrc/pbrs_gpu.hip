@@ -1133,7 +1133,8 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     // Scene::has_env_light for EnvLight::Constant (scene/src/lib.rs:96-102): !c.is_black()
     S.has_env = (d->env_kind != PBRS_ENV_CONSTANT || !(S.env[0] <= 0.0f && S.env[1] <= 0.0f && S.env[2] <= 0.0f)) ? 1u : 0u;
     S.refill_below = max_blas_height >= PBRS_LONG_WALK_HEIGHT ? PBRS_REFILL_BELOW_LONG : PBRS_REFILL_BELOW_SHORT;
-    if (const char* e = dev_env("PBRS_REFILL_BELOW")) S.refill_below = (uint32_t)std::atoi(e);  // developer override (A/B timing)
+    S.refill_below_shadow = max_blas_height >= PBRS_LONG_WALK_HEIGHT ? PBRS_REFILL_BELOW_LONG_SHADOW : PBRS_REFILL_BELOW_SHORT;
+    if (const char* e = dev_env("PBRS_REFILL_BELOW")) S.refill_below = S.refill_below_shadow = (uint32_t)std::atoi(e);  // developer override (A/B timing)
     // long walks: the levels a ray actually walks — the deepest BLAS, plus the TLAS where it is not scanned
     c->long_walks = (S.n_flat ? 0u : tlas_levels) + max_blas_height >= PBRS_LONG_WALK_HEIGHT;
     if (const char* e = dev_env("PBRS_LONG_WALKS")) c->long_walks = std::atoi(e) != 0;  // developer override (A/B timing)
