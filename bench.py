@@ -313,6 +313,11 @@ class Workload:
             "frame_mean_radiance": [float(x) for x in timed_frame.reshape(-1, 3).mean(axis=0)],
             "parity_window": window,
             "gather_ms": gather_ms,
+            # which instantiations of the traversal kernels the timed frames ran (include/pbrs_gpu.h, pbrs_stats::kernel_features_*)
+            "kernel_features": {"extend": int(per_frame[-1]["kernel_features_extend"]) if per_frame[-1] else None,
+                                "shadow": int(per_frame[-1]["kernel_features_shadow"]) if per_frame[-1] else None,
+                                "bits": "1 analytic shapes, 2 shading check, 4 scanned TLAS, 8 several node steps per round, 16 four-wide nodes, "
+                                        "32 full further node steps (scene beyond the last-level cache), 64 scene arrays in LDS, 128 TLAS in LDS"},
             "per_rank": per_rank,
             "band_imbalance": max(r["rows"] for r in per_rank) / (sum(r["rows"] for r in per_rank) / len(per_rank)),
             "roofline_inconsistent": inconsistent or False,
@@ -400,7 +405,7 @@ def main():
             r = wl.measure(args.also_steps, 1)
             wl.close()
             others[name] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "mrays_per_s", "mean_path_length", "config", "parity_window",
-                                              "roofline", "traversal", "stages_ms_per_step")}
+                                              "roofline", "traversal", "stages_ms_per_step", "kernel_features")}
             if name in ALSO_STRATA:
                 full = scenes_mod.CONFIGS[name]
                 others[name]["slice"] = {"spp_timed": ALSO_STRATA[name][0] * ALSO_STRATA[name][1], "spp_full": full[4] * full[5],
@@ -430,7 +435,7 @@ def main():
         }
         for k in ("mrays_per_s", "rays_per_step", "closest_rays_per_step", "shadow_rays_per_step", "shade_events_per_step", "mean_path_length",
                   "rays_per_sample", "paths_at_bounce", "shadow_rays_at_bounce", "invalid_samples", "frame_mean_radiance", "parity_window", "gather_ms",
-                  "per_rank", "band_imbalance",
+                  "per_rank", "band_imbalance", "kernel_features",
                   "roofline_inconsistent", "roofline", "traversal", "stages_ms_per_step", "stages"):
             line[k] = result[k]
         if others:

@@ -270,8 +270,8 @@ typedef struct pbrs_stats {
     uint32_t launches_extend, launches_shadow, launches_shade, passes;
     /* Which instantiation of the traversal kernels the render's passes launched (always filled): bit 0 analytic shapes, 1 per-candidate
      * shading check, 2 scanned TLAS, 3 several node steps per round (deep BLAS), 4 walks over four-wide nodes, 5 full further node
-     * steps (scene beyond the last-level cache, pbrs_set_cache_bytes), 6 scene arrays staged in LDS; 0x80000000: the instrumented
-     * variant (collect_counters). */
+     * steps (scene beyond the last-level cache, pbrs_set_cache_bytes), 6 scene arrays staged in LDS, 7 an unscanned TLAS staged in LDS;
+     * 0x80000000: the instrumented variant (collect_counters). */
     uint32_t kernel_features_extend, kernel_features_shadow;
     /* Queue sizes per bounce, summed over the passes of the render (filled with the work counters): paths_at_bounce[b] = rays
      * `scene.tlas.intersect` sees at `for bounces in 0..depth` iteration b (src/pathintegrator.rs:14-16), i.e. k_extend's queue;

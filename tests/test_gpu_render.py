@@ -664,3 +664,24 @@ def test_scene_beyond_the_cache_budget_takes_the_full_step_kernels(gpu_ctx):
     assert (bits(full) == bits(ref)).all()
     assert (bits(lean) == bits(ref)).all()
     assert st_full["invalid_samples"] == st_lean["invalid_samples"] == ost["nonfinite_samples"]
+
+
+def test_small_scenes_are_walked_from_lds_and_say_so(gpu_ctx):
+    """Round 4: the traversal kernels of a scene of a few KB read it from the block's LDS (PBRS_FEAT_LDS_SCENE, bit 6 of
+    pbrs_stats::kernel_features_*), those of a scene whose TLAS is too large for the wave's scan read the TLAS from there
+    (PBRS_FEAT_LDS_TOP, bit 7); a big scene gets neither.  Each against the oracle, bit for bit, with the counters' variant
+    (which stages nothing) agreeing."""
+    cases = [("c2", dict(width=96, height=96), 64, 0), ("c5", dict(width=128, height=72), 128, 64),
+             ("c4", dict(width=96, height=64, nx=64, nz=64), 0, 64 | 128)]
+    for name, kw, want, not_want in cases:
+        sb, c = scenes.build_config(name, **kw)
+        hs = pbrs_amd.HostScene(sb)
+        gpu_ctx.upload(hs)
+        img, st = gpu_ctx.render(2, 2, c["depth"], 17)
+        cnt, stc = gpu_ctx.render(2, 2, c["depth"], 17, counters=True)
+        ref, ost = OracleScene(sb).render(2, 2, c["depth"], 17)
+        for key in ("kernel_features_extend", "kernel_features_shadow"):
+            assert st[key] & want == want and not (st[key] & not_want), (name, key, st[key])
+            assert stc[key] & 0x80000000, (name, key, stc[key])
+        assert (bits(img) == bits(ref)).all() and (bits(cnt) == bits(ref)).all(), name
+        assert stc["closest_rays"] == ost["closest_rays"] and stc["shadow_rays"] == ost["shadow_rays"], name
