@@ -1,7 +1,7 @@
 #!/bin/bash
 # developer tool (GPU box): the whole GPU parity suite through the experimental walks of a developer build
 # (pbrs_amd/lib/abl_<name>.so built with -DPBRS_DEV_OVERRIDES: tools/ablate.sh "dev:-DPBRS_DEV_OVERRIDES"), one run per setting.
-#   usage: tools/dev_parity.sh dev "PBRS_GRID=3" "PBRS_CNODE=3" "PBRS_PAIR=3" "PBRS_WIDE=3"
+#   usage: tools/dev_parity.sh dev "PBRS_WIDE=3" "PBRS_WIDE=1"      (round 4: the four-wide closest walk of device/experimental/ is the one developer walk left)
 lib=$1; shift
 for v in "$@"; do
   echo "== $v"
