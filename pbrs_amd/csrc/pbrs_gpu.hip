@@ -68,6 +68,31 @@ struct pbrs_ctx {
     DevScene S{};
     uint32_t stack_depth = 0;
 
+    // Two sets of per-pass working memory (path state, queues, counters) and two streams.  Consecutive passes of a render alternate
+    // between the sets; a pass runs its bounces below overlap_from on the main stream and the rest — near-empty launches that end with
+    // the latency of their longest walks — on a second, high-priority stream, beside the full kernels of the next pass's first bounces
+    // (render_common, run_pass).  The fields below (state_mem .. counters) are the view of the set in use; use_pass_set swaps them.
+    struct PassSet {
+        void* state_mem = nullptr;
+        size_t cap_slots = 0;
+        PathState st{};
+        uint32_t* neeq = nullptr;
+        uint32_t* slow = nullptr;
+        uint32_t* counters = nullptr;
+        hipEvent_t accumulated = nullptr;  // the set's last k_accumulate has run (late stream): the set's memory is free for its next pass
+        hipEvent_t late = nullptr;         // the set's pass has run its bounces below pbrs_ctx::overlap_from (main stream): the late stream takes over
+        bool in_flight = false;            // `accumulated` has been recorded at least once
+    } pass_set[2];
+    int cur_set = 0;
+    hipStream_t main_stream = nullptr;  // the stream of set 0: the context's own, or the caller's (pbrs_set_stream)
+    hipStream_t second_stream = nullptr;  // the late stream: the context's own, high priority, ordered against the main one by events
+    bool overlap_passes = true;  // PBRS_OVERLAP_PASSES=0 in developer builds: every pass on the main stream, as in rounds 1-3
+    // The bounce from which a pass moves to the late stream (and the next pass starts behind it on the main one).  Same-box A/B lines in
+    // profiles/r04m_ab_pass_overlap.log: scenes that live in every XCD's L2 gain most from bounce 2 on (C2 +1.9 %, C3 +1.5 %, C5 +3.3 %
+    // against one stream; from 1: +1.3 / +1.2 / +2.7, from 3: 0 / +1.4 / +2.3), a scene that lives in the Infinity Cache from bounce 4 on
+    // (C4 +1.0 %; from 3: +0.8, from 2 or 5: +0.2) — two passes' full kernels side by side cost it its cache residency (streams by pass,
+    // every bounce overlapped: -2.6 %, profiles/r04l_ab_pass_overlap_streams_by_pass.log).
+    uint32_t overlap_from = 2;
     // working set
     size_t cap_slots = 0, cap_pixels = 0;
     void* state_mem = nullptr;    // every per-path array of PathState, carved out of one allocation
@@ -158,16 +183,32 @@ void free_scene(pbrs_ctx* c) {
     c->has_scene = false;
 }
 
+// The per-pass working memory in use (pbrs_ctx::pass_set): stores the context's view into the set it came from and loads set k,
+// whose stream becomes the context's.
+void use_pass_set(pbrs_ctx* c, int k) {
+    pbrs_ctx::PassSet& o = c->pass_set[c->cur_set];
+    o.state_mem = c->state_mem; o.cap_slots = c->cap_slots; o.st = c->st; o.neeq = c->neeq; o.slow = c->slow; o.counters = c->counters;
+    c->cur_set = k;
+    const pbrs_ctx::PassSet& n = c->pass_set[k];
+    c->state_mem = n.state_mem; c->cap_slots = n.cap_slots; c->st = n.st; c->neeq = n.neeq; c->slow = n.slow; c->counters = n.counters;
+    c->stream = c->main_stream;
+}
+
 void free_work(pbrs_ctx* c) {
     // capacities first: whatever happens below, no later call may take the old pointers for valid
-    c->cap_slots = c->cap_pixels = 0;
-    c->st = PathState{};
-    if (c->state_mem) (void)hipFree(c->state_mem);
+    for (int k = 0; k < 2; ++k) {
+        use_pass_set(c, k);
+        c->cap_slots = 0;
+        c->st = PathState{};
+        if (c->state_mem) (void)hipFree(c->state_mem);
+        c->state_mem = nullptr;
+        c->neeq = nullptr;
+        c->slow = nullptr;
+    }
+    use_pass_set(c, 0);
+    c->cap_pixels = 0;
     if (c->sum) (void)hipFree(c->sum);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
-    c->state_mem = nullptr;
-    c->neeq = nullptr;
-    c->slow = nullptr;
     c->sum = nullptr;
     c->rgb_dev = nullptr;
 }
@@ -369,7 +410,9 @@ uint32_t auto_samples_per_pass(const pbrs_ctx* c, const pbrs_render_params* p) {
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const uint64_t per_path = PBRS_STATE_BYTES_PER_PATH;  // path, hit, radiance, shadow-ray and nee records
             // what this context already holds for paths counts as available: the answer must not change between calls
-            const uint64_t fit = ((uint64_t)free_b + (uint64_t)c->cap_slots * per_path) / 4 / per_path;
+            // (... in both of its pass sets: a set may take a quarter of the memory, the two of them half)
+            const uint64_t held = (uint64_t)c->cap_slots + (uint64_t)c->pass_set[c->cur_set ^ 1].cap_slots;
+            const uint64_t fit = ((uint64_t)free_b + held * per_path) / 4 / per_path;
             if (fit < target) target = fit < (4ull << 20) ? (4ull << 20) : fit;
         }
         k = P >= target ? 1 : target / P;
@@ -499,7 +542,17 @@ void poll_split_probe(pbrs_ctx* c) {
 }
 
 // One pass: kc sample indices starting at `first` for every pixel of the tile.
-int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stats, Timer& tm) {
+// `handoff`: the pass moves to the late stream at bounce pbrs_ctx::overlap_from (at the latest for its k_accumulate: the late stream runs
+// the passes' accumulations in pass order, src/main.rs:205) and leaves the main stream to the next pass, which works in the other pass set.
+int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stats, Timer& tm, bool handoff = false) {
+    pbrs_ctx::PassSet& set = c->pass_set[c->cur_set];
+    // the set's memory is free once the pass that used it last has accumulated (two passes back, on the late stream)
+    if (handoff && set.in_flight) HIPCHK(c, hipStreamWaitEvent(c->stream, set.accumulated, 0));
+    auto to_late_stream = [&]() -> hipError_t {
+        hipError_t e = hipEventRecord(set.late, c->stream);
+        c->stream = c->second_stream;
+        return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, set.late, 0);
+    };
     const uint32_t P = rc.n_pixels;
     const uint32_t N = P * kc;
     rc.pass_first_sample = first;
@@ -535,6 +588,7 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     // this pass counts what k_extend's queue split keeps (the first path-integrator pass of an uploaded one-class scene)
     const bool probe_split = c->split_decision == 0 && !c->split_probe_in_flight && rc.integrator == PBRS_INTEGRATOR_PATH && c->S.n_classes <= 1u && c->split_queue && n_bounces > 0;
     for (uint32_t b = 0; b < n_bounces; ++b) {
+        if (handoff && b == c->overlap_from) HIPCHK(c, to_late_stream());
         // bounce b reads the path records of set b & 1 (k_raygen wrote set 0) and k_shade writes set (b + 1) & 1; the
         // queue length of bounce 0 is the pass size, later ones are counted on the device
         const uint32_t* cnt_in = b == 0 ? nullptr : act + b;
@@ -658,9 +712,14 @@ int run_pass(pbrs_ctx* c, RenderConst rc, uint32_t first, uint32_t kc, bool stat
     }
     if (stats)  // queue sizes of this pass, bounce by bounce (the counters are cleared at the start of every pass)
         hipLaunchKernelGGL(k_sum_bounce_counts, dim3(1), dim3(64), 0, c->stream, act, ns, N, n_bounces, c->bounce_acc);
+    if (handoff && c->stream != c->second_stream) HIPCHK(c, to_late_stream());
     if (tm.begin(4)) return fail(c, PBRS_E_DEVICE, "event record failed");
     hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->st, c->sum, P, kc, rc.chunk_pixels, rc.w, rc.tiles8_per_row, c->nonfinite);
     tm.end();
+    if (handoff) {
+        HIPCHK(c, hipEventRecord(set.accumulated, c->stream));
+        set.in_flight = true;
+    }
     HIPCHK(c, hipGetLastError());
     return PBRS_OK;
 }
@@ -688,11 +747,31 @@ int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params*
     if (c->pending_times) HIPCHK(c, hipEventRecord(c->total_ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->sum, 0, 3 * (size_t)P * sizeof(float), c->stream));
     uint32_t passes = 0;
+    // Where the render has more than one pass, passes alternate between the two pass sets and hand their late bounces to the second
+    // stream: those are near-empty launches that end with the latency of their longest walks (C4: 47 ms per frame in kernels that leave
+    // most of the chip idle, profiles/r04k_trace_gaps_c4.log) — the next pass's first bounces, queued behind the hand-over on the main
+    // stream, fill it.  The instrumented render keeps one stream (its counters are per pass).
+    const bool two = c->overlap_passes && !stats && spp > K;
+    if (two) {
+        use_pass_set(c, 1);
+        rcode = ensure_work(c, (size_t)P * K, P);
+        use_pass_set(c, 0);
+        if (rcode) return rcode;
+    }
     for (uint32_t first = 0; first < spp; first += K) {
         uint32_t kc = spp - first < K ? spp - first : K;
-        rcode = run_pass(c, rc, first, kc, stats, tm);
-        if (rcode) return rcode;
+        if (two) use_pass_set(c, (int)(passes & 1u));  // (also: back to the main stream)
+        rcode = run_pass(c, rc, first, kc, stats, tm, two);
+        if (rcode) {
+            use_pass_set(c, 0);
+            return rcode;
+        }
         ++passes;
+    }
+    if (two) {
+        const hipEvent_t last = c->pass_set[c->cur_set].accumulated;
+        use_pass_set(c, 0);
+        HIPCHK(c, hipStreamWaitEvent(c->main_stream, last, 0));  // the late stream has run every pass's accumulation, in order
     }
     hipLaunchKernelGGL(k_finalize, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->sum, rgb_device, P, 1.0f / (float)spp);
     if (c->pending_times) HIPCHK(c, hipEventRecord(c->total_ev[1], c->stream));
@@ -815,7 +894,17 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
     // a non-blocking stream: work another library queues on the legacy default stream (torch's copies in bench.py) neither
     // waits for the frames queued here nor holds them up
     bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
-    c->stream = c->own_stream;
+    c->stream = c->main_stream = c->own_stream;
+    {
+        int least = 0, greatest = 0;  // (numerically lower = higher priority)
+        ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+             hipStreamCreateWithPriority(&c->second_stream, hipStreamNonBlocking, greatest) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&c->pass_set[0].accumulated, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->pass_set[1].accumulated, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->pass_set[0].late, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->pass_set[1].late, hipEventDisableTiming) == hipSuccess;
+    if (const char* e = dev_env("PBRS_OVERLAP_PASSES")) c->overlap_passes = std::atoi(e) != 0;
     if (const char* e = dev_env("PBRS_SORT_CLASSES")) c->sort_classes = std::atoi(e) != 0;
     if (const char* e = dev_env("PBRS_SPLIT_LAMBERT")) c->split_lambert = std::atoi(e) != 0;
     if (const char* e = dev_env("PBRS_SPLIT_FOURIER")) c->split_fourier = std::atoi(e) != 0;
@@ -825,7 +914,8 @@ int pbrs_create(int device_ordinal, pbrs_ctx** out) {
         ok = hipEventCreate(&ev) == hipSuccess;
         if (ok) c->total_ev.push_back(ev);
     }
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) == hipSuccess &&
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->pass_set[1].counters), kCounterWords * sizeof(uint32_t)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&c->counters), kCounterWords * sizeof(uint32_t)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&c->gcnt), 2 * sizeof(GlobalCounters)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&c->nonfinite), sizeof(unsigned long long)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&c->bounce_acc), (2 * PBRS_STATS_MAX_BOUNCES + 2) * sizeof(unsigned long long)) == hipSuccess &&
@@ -846,9 +936,16 @@ void pbrs_destroy(pbrs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->second_stream) (void)hipStreamSynchronize(c->second_stream);
     free_scene(c);
-    free_work(c);
+    free_work(c);  // (leaves pass set 0 in use)
     if (c->counters) (void)hipFree(c->counters);
+    if (c->pass_set[1].counters) (void)hipFree(c->pass_set[1].counters);
+    for (int k = 0; k < 2; ++k)
+        if (c->pass_set[k].accumulated) (void)hipEventDestroy(c->pass_set[k].accumulated);
+    for (int k = 0; k < 2; ++k)
+        if (c->pass_set[k].late) (void)hipEventDestroy(c->pass_set[k].late);
+    if (c->second_stream) (void)hipStreamDestroy(c->second_stream);
     if (c->gcnt) (void)hipFree(c->gcnt);
     if (c->nonfinite) (void)hipFree(c->nonfinite);
     if (c->bounce_acc) (void)hipFree(c->bounce_acc);
@@ -867,7 +964,8 @@ const char* pbrs_last_error(const pbrs_ctx* c) { return c ? c->error.c_str() : "
 
 int pbrs_set_stream(pbrs_ctx* c, void* hip_stream) {
     if (!c) return PBRS_E_INVALID;
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->main_stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->stream = c->main_stream;  // (pass set 0 is the one in use between calls)
     return PBRS_OK;
 }
 
@@ -997,6 +1095,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     uint32_t depth = std::max(tlas_levels, tlas_levels - 1u + max_blas_height);
     if ((size_t)depth * kBlock * sizeof(uint32_t) > kLdsBytesPerCU / 2) return fail(c, PBRS_E_LIMIT, "traversal stack exceeds the LDS budget");
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->second_stream);
     free_scene(c);
     DevScene S{};
     int rc;
@@ -1141,6 +1240,8 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     // lean further node steps where the walks' arrays live in the caches, full ones where their fetches go to HBM (kernels.h)
     c->walk_bytes = walk_bytes;
     c->full_steps = walk_bytes > c->cache_bytes;
+    c->overlap_from = walk_bytes <= (4ull << 20) ? 2u : 4u;  // one XCD's L2 holds the arrays the walks read, or not (pbrs_ctx::overlap_from)
+    if (const char* e = dev_env("PBRS_OVERLAP_FROM")) c->overlap_from = (uint32_t)std::atoi(e);  // developer override (A/B timing)
     // the leaf copies serve k_shadow up to PBRS_FLAT_TLAS_MAX_ANYHIT instances, k_extend up to PBRS_FLAT_TLAS_MAX
     c->shadow_flat = S.n_flat != 0u;
     const uint32_t flat_feature = (S.n_flat != 0u && d->n_instances <= PBRS_FLAT_TLAS_MAX) ? PBRS_FEAT_FLAT_TLAS : 0u;

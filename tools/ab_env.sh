@@ -1,8 +1,15 @@
 #!/bin/bash
-# developer tool (GPU box): full-size bench lines of the built library under different environments, one after the other on the
-# same GPU.   usage: CFGS="c3 c5" tools/ab_env.sh "PBRS_SHADE_SPEC=7" ""
-cfgs=${CFGS:-c4 c2 c3}
-for c in $cfgs; do for v in "$@"; do
-  line=$(env $v timeout -k 10 300 python bench.py --config $c --also "" --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline $BENCH_EXTRA 2>&1 | grep '^{"metric"')
-  echo "$c [$v] $(echo "$line" | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("%.1f Msamples/s %.0f Mrays/s" % (d["value"], d["mrays_per_s"]), {k: round(v,1) for k,v in d["stages_ms_per_step"].items() if k.startswith("ms_")})' 2>&1 | tail -1)"
-done; done
+# developer tool (GPU box): A/B of developer overrides (environment variables a -DPBRS_DEV_OVERRIDES build reads) on ONE box.
+#   usage: tools/ab_env.sh LIBNAME "<bench args>" "VAR=val [VAR=val]" ...     (LIBNAME: pbrs_amd/lib/abl_<LIBNAME>.so; "" = no override)
+lib=$PWD/pbrs_amd/lib/abl_$1.so; args=$2; shift 2
+for v in "$@"; do
+  env $v PBRS_GPU_LIB=$lib timeout -k 10 300 python bench.py $args --no-cpu-baseline --no-parity-window > gpurun_out/abenv.log 2>&1 || { echo "== $v FAILED"; tail -3 gpurun_out/abenv.log; exit 1; }
+  python - "$v" <<'PY'
+import json, sys
+for l in open("gpurun_out/abenv.log"):
+    if l.startswith('{"metric"'):
+        d = json.loads(l)
+        rows = [(d["config"]["scene"], d)] + list(d.get("other_configs", {}).items())
+        print("== %-28s" % sys.argv[1], " | ".join("%s %.1f (%.1f ms)" % (n, r["value"], r["ms_per_step"]) for n, r in rows), flush=True)
+PY
+done
