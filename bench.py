@@ -230,6 +230,16 @@ class Workload:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, gather_ms = float(t[0].item()), float(t[1].item())
 
+        # Untimed: one frame with every pass on one stream, for per-stage milliseconds that are exclusive times (in the timed frames a pass's
+        # late bounces run on a second stream beside the next pass's first bounces: their event brackets overlap and do not add up)
+        serial_times = None
+        if self.my_rows:
+            self.ctx.set_pass_overlap(False)
+            try:
+                _, (sst,) = self.frames(1, timing=True)
+            finally:
+                self.ctx.set_pass_overlap(True)
+            serial_times = {k: v for k, v in sst.items() if k.startswith("ms_")}
         # Untimed: instrumented frame for ray / node / primitive counts (deterministic, equal to the timed work).
         frame, (cst,) = self.frames(1, counters=True)
         nb = 16
@@ -353,6 +363,11 @@ class Workload:
             },
             "traversal": trav,
             "stages_ms_per_step": times,
+            "stages_overlap": "a render of several passes runs each pass's late bounces on a second stream beside the next pass's first bounces "
+                              "(pbrs_set_pass_overlap): stages_ms_per_step are HIP-event brackets on the launching stream over the timed frames and "
+                              "include the time a kernel shares the chip with the other stream's, so they do not add up to ms_total; "
+                              "stages_ms_serial is one untimed frame with the overlap off (rank 0), where they do",
+            "stages_ms_serial": serial_times,
             "stages": rep,
         }
 
@@ -405,7 +420,7 @@ def main():
             r = wl.measure(args.also_steps, 1)
             wl.close()
             others[name] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "mrays_per_s", "mean_path_length", "config", "parity_window",
-                                              "roofline", "traversal", "stages_ms_per_step", "kernel_features")}
+                                              "roofline", "traversal", "stages_ms_per_step", "stages_ms_serial", "kernel_features")}
             if name in ALSO_STRATA:
                 full = scenes_mod.CONFIGS[name]
                 others[name]["slice"] = {"spp_timed": ALSO_STRATA[name][0] * ALSO_STRATA[name][1], "spp_full": full[4] * full[5],
@@ -436,7 +451,7 @@ def main():
         for k in ("mrays_per_s", "rays_per_step", "closest_rays_per_step", "shadow_rays_per_step", "shade_events_per_step", "mean_path_length",
                   "rays_per_sample", "paths_at_bounce", "shadow_rays_at_bounce", "invalid_samples", "frame_mean_radiance", "parity_window", "gather_ms",
                   "per_rank", "band_imbalance", "kernel_features",
-                  "roofline_inconsistent", "roofline", "traversal", "stages_ms_per_step", "stages"):
+                  "roofline_inconsistent", "roofline", "traversal", "stages_ms_per_step", "stages_overlap", "stages_ms_serial", "stages"):
             line[k] = result[k]
         if others:
             line["other_configs"] = others

@@ -292,6 +292,13 @@ const char* pbrs_last_error(const pbrs_ctx*);
  * created hipStreamNonBlocking: see "Stream ordering" above. */
 int pbrs_set_stream(pbrs_ctx*, void* hip_stream);
 
+/* A render of several passes hands every pass's late bounces (near-empty launches that end with the latency of their longest walks) to a
+ * second, high-priority stream of the context, where they run beside the next pass's first bounces; the passes' samples still reach the
+ * pixel sums in pass order (src/main.rs:205), so the image does not depend on it.  On by default; 0 keeps every pass on the context's
+ * stream — what a host wants when it reads the per-stage milliseconds of pbrs_stats as exclusive times (with the overlap a stage's
+ * event brackets include the time its kernels share the chip with the other stream's). */
+int pbrs_set_pass_overlap(pbrs_ctx*, int enabled);
+
 /* The size of the last-level cache the per-scene kernel choices of pbrs_upload_scene assume (0 = the default, 256 MiB: MI355X's
  * Infinity Cache).  A scene whose traversal arrays (BVH nodes, triangle vertices, instance records) exceed it gets the traversal
  * kernels tuned for node fetches that go to HBM.  Takes effect at the next pbrs_upload_scene; the image never depends on it. */

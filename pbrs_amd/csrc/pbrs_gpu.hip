@@ -969,6 +969,12 @@ int pbrs_set_stream(pbrs_ctx* c, void* hip_stream) {
     return PBRS_OK;
 }
 
+int pbrs_set_pass_overlap(pbrs_ctx* c, int enabled) {
+    if (!c) return PBRS_E_INVALID;
+    c->overlap_passes = enabled != 0;
+    return PBRS_OK;
+}
+
 int pbrs_set_cache_bytes(pbrs_ctx* c, uint64_t bytes) {
     if (!c) return PBRS_E_INVALID;
     c->cache_bytes = bytes ? bytes : (256ull << 20);

@@ -685,3 +685,32 @@ def test_small_scenes_are_walked_from_lds_and_say_so(gpu_ctx):
             assert stc[key] & 0x80000000, (name, key, stc[key])
         assert (bits(img) == bits(ref)).all() and (bits(cnt) == bits(ref)).all(), name
         assert stc["closest_rays"] == ost["closest_rays"] and stc["shadow_rays"] == ost["shadow_rays"], name
+
+
+def test_passes_overlapped_on_two_streams_render_the_same_frame(gpu_ctx):
+    """A render of several passes hands each pass's late bounces to a second stream, beside the next pass's first bounces
+    (pbrs_set_pass_overlap, on by default; two sets of per-pass memory).  The passes' samples reach the pixel sums in pass order
+    whatever the streams do: five passes of two samples (and a last one of one) give the oracle's frame bit for bit, overlapped or
+    not, on a scene that hands over at bounce 2 (C3) and on one that does at bounce 4 (a terrain beyond one XCD's L2), for both
+    integrators; per-stage times are filled either way."""
+    for name, kw in (("c3", dict(width=96, height=64)), ("c4", dict(width=96, height=64, nx=192, nz=192))):
+        sb, c = scenes.build_config(name, **kw)
+        hs = pbrs_amd.HostScene(sb)
+        gpu_ctx.upload(hs)
+        osc = OracleScene(sb)
+        for integrator in ("path", "direct"):
+            ref, _ = osc.render(3, 3, c["depth"], 23, integrator=integrator)
+            try:
+                on, st_on = gpu_ctx.render(3, 3, c["depth"], 23, samples_per_pass=2, timing=True, integrator=integrator)
+                gpu_ctx.set_pass_overlap(False)
+                off, st_off = gpu_ctx.render(3, 3, c["depth"], 23, samples_per_pass=2, timing=True, integrator=integrator)
+            finally:
+                gpu_ctx.set_pass_overlap(True)
+            one, _ = gpu_ctx.render(3, 3, c["depth"], 23, integrator=integrator)  # a single pass
+            assert st_on["passes"] == st_off["passes"] == 5
+            assert (bits(on) == bits(ref)).all() and (bits(off) == bits(ref)).all() and (bits(one) == bits(ref)).all(), (name, integrator)
+            assert st_on["ms_total"] > 0 and st_off["ms_extend"] > 0 and st_on["invalid_samples"] == st_off["invalid_samples"]
+    # consecutive overlapped frames through the same two sets of memory
+    a, _ = gpu_ctx.render(3, 3, c["depth"], 5, samples_per_pass=4)
+    b, _ = gpu_ctx.render(3, 3, c["depth"], 5, samples_per_pass=4)
+    assert (bits(a) == bits(b)).all()
