@@ -270,7 +270,7 @@ typedef struct pbrs_stats {
     uint32_t launches_extend, launches_shadow, launches_shade, passes;
     /* Which instantiation of the traversal kernels the render's passes launched (always filled): bit 0 analytic shapes, 1 per-candidate
      * shading check, 2 scanned TLAS, 3 several node steps per round (deep BLAS), 4 walks over four-wide nodes, 5 full further node
-     * steps (scene beyond the last-level cache, pbrs_set_cache_bytes), 6 scene arrays staged in LDS, 7 an unscanned TLAS staged in LDS;
+     * steps (a scene with coordinates outside the guarded range of the division-free box test), 6 scene arrays staged in LDS, 7 an unscanned TLAS staged in LDS;
      * 0x80000000: the instrumented variant (collect_counters). */
     uint32_t kernel_features_extend, kernel_features_shadow;
     /* Queue sizes per bounce, summed over the passes of the render (filled with the work counters): paths_at_bounce[b] = rays
@@ -298,11 +298,6 @@ int pbrs_set_stream(pbrs_ctx*, void* hip_stream);
  * stream — what a host wants when it reads the per-stage milliseconds of pbrs_stats as exclusive times (with the overlap a stage's
  * event brackets include the time its kernels share the chip with the other stream's). */
 int pbrs_set_pass_overlap(pbrs_ctx*, int enabled);
-
-/* The size of the last-level cache the per-scene kernel choices of pbrs_upload_scene assume (0 = the default, 256 MiB: MI355X's
- * Infinity Cache).  A scene whose traversal arrays (BVH nodes, triangle vertices, instance records) exceed it gets the traversal
- * kernels tuned for node fetches that go to HBM.  Takes effect at the next pbrs_upload_scene; the image never depends on it. */
-int pbrs_set_cache_bytes(pbrs_ctx*, uint64_t bytes);
 
 /* Copies the flattened scene into HBM.  Stands for building `Scene` (scene/src/lib.rs:36-63). */
 int pbrs_upload_scene(pbrs_ctx*, const pbrs_scene_desc*);

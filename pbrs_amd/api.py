@@ -75,7 +75,7 @@ HIT_DTYPE = np.dtype([("t", np.float32), ("inst", np.uint32), ("prim", np.uint32
 NUMERIC_FNS = {"sin": 0, "cos": 1, "tan": 2, "atan": 3, "atan2": 4, "acos": 5, "exp": 6, "ln": 7, "hypot": 8, "div": 9,
                "sqrt": 10, "asin": 11, "powi": 12, "fract": 13, "floor": 14, "box_quotient": 15}
 
-GPU_SYMBOLS = ["pbrs_create", "pbrs_destroy", "pbrs_last_error", "pbrs_set_stream", "pbrs_set_pass_overlap", "pbrs_set_cache_bytes", "pbrs_upload_scene", "pbrs_render_tile",
+GPU_SYMBOLS = ["pbrs_create", "pbrs_destroy", "pbrs_last_error", "pbrs_set_stream", "pbrs_set_pass_overlap", "pbrs_upload_scene", "pbrs_render_tile",
                "pbrs_render_tile_device", "pbrs_collect_stats", "pbrs_intersect_rays", "pbrs_last_intersect_info", "pbrs_camera_rays",
                "pbrs_numeric_eval", "pbrs_render_sample_radiance"]
 HOST_SYMBOLS = ["pbrs_host_scene_build", "pbrs_host_scene_free", "pbrs_host_scene_desc", "pbrs_host_scene_camera",
@@ -134,7 +134,6 @@ def gpu_lib():
         L.pbrs_last_error.restype = C.c_char_p
         L.pbrs_last_error.argtypes = [C.c_void_p]
         L.pbrs_set_stream.argtypes = [C.c_void_p, C.c_void_p]
-        L.pbrs_set_cache_bytes.argtypes = [C.c_void_p, C.c_uint64]
         L.pbrs_set_pass_overlap.argtypes = [C.c_void_p, C.c_int]
         L.pbrs_upload_scene.argtypes = [C.c_void_p, C.c_void_p]
         L.pbrs_render_tile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -263,10 +262,6 @@ class Context:
     def set_pass_overlap(self, enabled):
         """Late bounces of a pass beside the next pass's first bounces, on a second stream (default on; include/pbrs_gpu.h)."""
         self._check(self._L.pbrs_set_pass_overlap(self._h, int(bool(enabled))), "pbrs_set_pass_overlap")
-
-    def set_cache_bytes(self, nbytes):
-        """The last-level cache size the per-scene kernel choices of the next upload assume (0: the default, 256 MiB)."""
-        self._check(self._L.pbrs_set_cache_bytes(self._h, int(nbytes)), "pbrs_set_cache_bytes")
 
     def upload(self, host_scene):
         self._check(self._L.pbrs_upload_scene(self._h, C.addressof(host_scene.desc)), "pbrs_upload_scene")

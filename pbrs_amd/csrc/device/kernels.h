@@ -217,11 +217,12 @@ PD void flush_counters(const Cnt<STATS>& cnt, GlobalCounters* g, bool valid, uin
 // boundary, who holds a leaf, who is done) then run a third as often.  C4 (23 levels), ms per frame extend / shadow at
 // 1 / 2 / 3 / 4 / 6 steps: 562 / 530 / 523 / 523 / 537 and 321 / 301 / 295 / 295 / 301; short walks lose (two steps: C2 -2 %,
 // C3 -1 %: the later steps run at few lanes) and keep one.
-// A round's further node steps are LEAN ones (traverse.h, node_step_fast: pop, test, push; a lane at the floor of its tree waits for
-// the round's first step) where the scene's nodes live in the caches — C4 +2 % — and FULL ones (PBRS_FEAT_FULL_STEPS) where node
-// fetches go to HBM: there a round is long and the lanes a lean step leaves waiting are what the wave's time is made of (c4xl: 742
-// against 657 Msamples/s, profiles/r03m_ab_c4xl_lean_steps.log).  pbrs_upload_scene chooses per scene by the size of what the walks
-// read against the last-level cache (pbrs_set_cache_bytes).
+// A round's further node steps are LEAN ones (traverse.h, node_step_fast: pop, test, push; a lane at the floor of its tree, or on the
+// literal divisions, waits for the round's first step): C4 +2 %, c4xl +2.6 % (profiles/r04p_ab_c4xl_fast_box_test_lean_vs_full.log).  A scene
+// whose node coordinates leave the guarded range of the division-free box test walks EVERY ray on the literal divisions, which the
+// lean steps do not carry — they would all sit idle: such a scene gets FULL further steps (PBRS_FEAT_FULL_STEPS, pbrs_upload_scene).
+// (Round 3 measured "lean steps cost the out-of-cache scene 11 %" on c4xl: that scene had lost the division-free test over three
+// vertex heights below 2^-20 — a bound since lowered to 2^-60, pbrs_gpu.hip — and with it everything built on it.)
 #define PBRS_MORE_NODE_STEPS(walk, S, stk, cnt, NSTEPS, FULL)                      \
     do {                                                                           \
         _Pragma("unroll") for (uint32_t k_ = 1; k_ < (NSTEPS); ++k_) {             \

@@ -81,7 +81,7 @@ struct DevScene {
 #define PBRS_FEAT_WIDE 16u          // kernels only: the walks over four-wide nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
 #define PBRS_FEAT_LDS_TOP 128u      // kernels only: the head of DevScene::nodes — a TLAS too large to scan — is copied into the block's LDS (scenes whose arrays do not fit as a whole)
 #define PBRS_FEAT_LDS_SCENE 64u     // kernels only: the arrays the walks read are copied into the block's LDS at kernel start (scenes of a few KB; kernels.h)
-#define PBRS_FEAT_FULL_STEPS 32u    // kernels only (with PBRS_FEAT_LONG_WALKS): a round's further node steps are full steps (kernels.h): scenes beyond the last-level cache
+#define PBRS_FEAT_FULL_STEPS 32u    // kernels only (with PBRS_FEAT_LONG_WALKS): a round's further node steps are full steps (kernels.h): scenes outside the guarded range of the division-free box test
 #define PBRS_FLAT_TLAS_MIN 2u
 // Largest TLAS the wave scans instead of walking (tools/tlas_probe.py, C5's scene family at 960x540, ms per 64 spp, walk vs
 // scan): closest hit 4.84 / 4.74 at 20 instances, 5.10 / 5.28 at 24, 5.66 / 6.15 at 30 — the scan only filters there and every

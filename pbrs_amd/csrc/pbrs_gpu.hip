@@ -119,8 +119,7 @@ struct pbrs_ctx {
     bool split_lambert = true;     // PBRS_SPLIT_LAMBERT=0 in the environment: one general k_shade launch for all classes (A/B timing)
     uint32_t shade_spec = 0;       // PBRS_SHADE_*: what k_shade<PATH> may leave out for this scene
     bool long_walks = false;       // a BLAS of PBRS_LONG_WALK_HEIGHT levels or more: the PBRS_FEAT_LONG_WALKS kernels
-    bool full_steps = false;       // ... whose further node steps are full ones (PBRS_FEAT_FULL_STEPS): what the walks read exceeds the last-level cache
-    uint64_t cache_bytes = 256ull << 20;  // the last-level cache the per-scene choices assume (MI355X: 256 MiB Infinity Cache); pbrs_set_cache_bytes
+    bool full_steps = false;       // ... whose further node steps are full ones (PBRS_FEAT_FULL_STEPS): a scene outside the guarded range of the division-free box test
     uint64_t walk_bytes = 0;       // bytes of the arrays the walks read (nodes, wide nodes, triangle vertices, instances)
     uint32_t shade_lds = 0;        // PBRS_SHADE_LDS_*: what k_shade<PATH>'s untextured variants stage in LDS for this scene (kernels.h)
     size_t shade_lds_bytes = 0;
@@ -975,12 +974,6 @@ int pbrs_set_pass_overlap(pbrs_ctx* c, int enabled) {
     return PBRS_OK;
 }
 
-int pbrs_set_cache_bytes(pbrs_ctx* c, uint64_t bytes) {
-    if (!c) return PBRS_E_INVALID;
-    c->cache_bytes = bytes ? bytes : (256ull << 20);
-    return PBRS_OK;
-}
-
 int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     if (!c || !d) return PBRS_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1105,12 +1098,18 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     free_scene(c);
     DevScene S{};
     int rc;
-    // The division-free box test (device/traverse.h) is exact when every node coordinate b is finite,
-    // |b| <= 2^40 and (b == 0 or |b| >= 2^-20); otherwise every lane uses the literal divisions.
+    // The division-free box test (device/traverse.h) is exact when every node coordinate b is finite, |b| <= 2^40 and (b == 0 or
+    // |b| >= 2^-60) — the range of a ray's origin components (origin_in_range); otherwise every lane uses the literal divisions.
+    // With o and b both zero or at least 2^-60 the numerator RN(o - b) is zero or at least 2^-83, its first quotient q0 = nn nr at least
+    // 2^-123 (normal: rounded at full precision), the residual e = d q0 + nn a multiple of 2^-131 (exact, if subnormal: the kernels run
+    // with f32 denormals on, .amdhsa_float_denorm_mode_32 3) and the result normal: the three instructions return RN(n / d) as they
+    // do at any other scale (tools/microbench/div_exhaustive.hip).  Rounds 1-3 asked 2^-20 of the box coordinates — a bound of the
+    // f64 route of rounds 1-2 that the f32 quotient inherited: c4xl's 8.4 M vertices hold three heights below it (1.6e-7, 7.4e-7,
+    // -9.8e-8), and the WHOLE scene walked on the literal divisions, its lean node steps sitting idle (round 3's "-11 % out of cache").
     {
         auto coord_ok = [](float b) {
             uint32_t u = pn_bits(b) & 0x7fffffffu, e = u >> 23;
-            return u == 0u || (e >= 127u - 20u && e <= 127u + 40u);
+            return u == 0u || (e >= 127u - 60u && e <= 127u + 40u);
         };
         bool ok = true;
         for (uint32_t i = 0; i < d->n_tlas_nodes && ok; ++i)
@@ -1243,9 +1242,11 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     // long walks: the levels a ray actually walks — the deepest BLAS, plus the TLAS where it is not scanned
     c->long_walks = (S.n_flat ? 0u : tlas_levels) + max_blas_height >= PBRS_LONG_WALK_HEIGHT;
     if (const char* e = dev_env("PBRS_LONG_WALKS")) c->long_walks = std::atoi(e) != 0;  // developer override (A/B timing)
-    // lean further node steps where the walks' arrays live in the caches, full ones where their fetches go to HBM (kernels.h)
+    // lean further node steps for rays on the division-free box test; a scene whose coordinates leave its guarded range walks every
+    // ray on the literal divisions, which the lean steps do not carry: full steps (kernels.h)
     c->walk_bytes = walk_bytes;
-    c->full_steps = walk_bytes > c->cache_bytes;
+    c->full_steps = S.fast_slab == 0u;
+    if (const char* e = dev_env("PBRS_FULL_STEPS")) c->full_steps = std::atoi(e) != 0;  // developer override (A/B timing)
     c->overlap_from = walk_bytes <= (4ull << 20) ? 2u : 4u;  // one XCD's L2 holds the arrays the walks read, or not (pbrs_ctx::overlap_from)
     if (const char* e = dev_env("PBRS_OVERLAP_FROM")) c->overlap_from = (uint32_t)std::atoi(e);  // developer override (A/B timing)
     // the leaf copies serve k_shadow up to PBRS_FLAT_TLAS_MAX_ANYHIT instances, k_extend up to PBRS_FLAT_TLAS_MAX

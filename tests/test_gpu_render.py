@@ -640,30 +640,30 @@ def test_wide_walk_kernels_and_their_slow_list_match_oracle(gpu_ctx):
     assert (gh["inst"] != 0xffffffff).mean() > 0.3
 
 
-def test_scene_beyond_the_cache_budget_takes_the_full_step_kernels(gpu_ctx):
-    """pbrs_upload_scene chooses a round's further node steps per scene (kernels.h): lean ones where the arrays the walks read fit
-    the last-level cache, full ones (PBRS_FEAT_FULL_STEPS) where they do not — c4xl's 2.2 GB against the 256 MiB Infinity Cache.
-    The suite does not ship a 2 GB scene: the cache budget is lowered instead (pbrs_set_cache_bytes), the same deep terrain is
-    rendered through both sets of kernels and both frames equal the oracle's bit for bit."""
+def test_scene_outside_the_guarded_range_takes_the_full_step_kernels(gpu_ctx):
+    """A round's further node steps are lean ones (kernels.h): they carry the division-free box test only.  A scene whose node
+    coordinates leave that test's guarded range walks every ray on the literal divisions — the lean steps would sit idle — and
+    gets the kernels with full further steps (PBRS_FEAT_FULL_STEPS, bit 5 of pbrs_stats::kernel_features_*); the same deep terrain
+    with the offending height (2^-61: below the 2^-60 a coordinate may have) moved to zero gets the lean ones.  Both frames equal
+    the oracle's bit for bit."""
     FULL = 32
-    sb, c = scenes.build_config("c4", width=160, height=96, nx=128, nz=128)
-    hs = pbrs_amd.HostScene(sb)
-    ref, ost = OracleScene(sb).render(2, 2, c["depth"], 21)
-    try:
-        gpu_ctx.set_cache_bytes(1 << 20)  # the scene's nodes and triangles are a few MB
+    frames = {}
+    for name, height in (("outside", 2.0 ** -61), ("inside", 0.0)):
+        sb, c = scenes.build_config("c4", width=160, height=96, nx=128, nz=128)
+        pos = sb.meshes[0][0]  # the terrain's vertex positions (pbrs_amd/spec.py, SceneBuilder.mesh): one height replaced
+        pos[len(pos) // 2, 1] = height
+        hs = pbrs_amd.HostScene(sb)
         gpu_ctx.upload(hs)
-        full, st_full = gpu_ctx.render(2, 2, c["depth"], 21)
-        assert st_full["kernel_features_extend"] & FULL and st_full["kernel_features_shadow"] & FULL, st_full
-        assert st_full["kernel_features_extend"] & 8 and st_full["kernel_features_shadow"] & 16  # several node steps per round; wide k_shadow
-    finally:
-        gpu_ctx.set_cache_bytes(0)
-    gpu_ctx.upload(hs)
-    lean, st_lean = gpu_ctx.render(2, 2, c["depth"], 21)
-    assert not (st_lean["kernel_features_extend"] & FULL) and not (st_lean["kernel_features_shadow"] & FULL), st_lean
-    assert np.isfinite(ref).all()
-    assert (bits(full) == bits(ref)).all()
-    assert (bits(lean) == bits(ref)).all()
-    assert st_full["invalid_samples"] == st_lean["invalid_samples"] == ost["nonfinite_samples"]
+        img, st = gpu_ctx.render(2, 2, c["depth"], 21)
+        ref, ost = OracleScene(sb).render(2, 2, c["depth"], 21)
+        assert np.isfinite(ref).all() and (bits(img) == bits(ref)).all(), name
+        assert st["invalid_samples"] == ost["nonfinite_samples"]
+        assert st["kernel_features_extend"] & 8, st  # several node steps per round: the further steps exist
+        frames[name] = st
+    assert frames["outside"]["kernel_features_extend"] & FULL and frames["outside"]["kernel_features_shadow"] & FULL, frames["outside"]
+    assert not (frames["outside"]["kernel_features_shadow"] & 16)  # no four-wide k_shadow without the division-free test
+    assert not (frames["inside"]["kernel_features_extend"] & FULL) and not (frames["inside"]["kernel_features_shadow"] & FULL), frames["inside"]
+    assert frames["inside"]["kernel_features_shadow"] & 16
 
 
 def test_small_scenes_are_walked_from_lds_and_say_so(gpu_ctx):

@@ -238,9 +238,9 @@ def test_empty_and_degenerate_batches(gpu_ctx):
 
 @pytest.mark.parametrize("scale", [1e-9, 1e-3, 1.0, 1e6, 1e13])
 def test_box_test_fallback_ranges(gpu_ctx, scale):
-    """The f64-reciprocal box test is only taken inside its proven range (node coordinates 0 or 2^-20..2^40, ray
-    components in range); scenes and rays outside it must take the reference's literal divisions and still agree bit
-    for bit.  Same geometry at five scales, rays with zero, tiny and huge components."""
+    """The division-free box test is only taken inside its proven range (node coordinates and origin components 0 or
+    2^-60..2^40, direction components 2^-40..2^40); scenes and rays outside it must take the reference's literal divisions
+    and still agree bit for bit.  Same geometry at five scales, rays with zero, tiny and huge components."""
     from pbrs_amd.spec import SceneBuilder, Transform, deg
     s = np.float32(scale)
     sb = SceneBuilder()
@@ -275,3 +275,56 @@ def test_box_test_fallback_ranges(gpu_ctx, scale):
 def scenes_quad(sb, s):
     from pbrs_amd import scenes
     return scenes.quad_mesh(sb, (-3 * s, -1.2 * s, -3 * s), (3 * s, -1.2 * s, -3 * s), (-3 * s, -1.2 * s, 3 * s), (3 * s, -1.2 * s, 3 * s), (0, 1, 0))
+
+
+@pytest.mark.parametrize("tiniest", [2.0 ** -60, 2.0 ** -61])
+def test_tiny_node_coordinates_and_the_fast_box_test(gpu_ctx, tiniest):
+    """Round 4: box coordinates may go down to 2^-60 (as a ray's origin components may) before a scene loses the division-free box
+    test — c4xl's 8.4 M vertices hold heights of 1.6e-7 and -9.8e-8, below round 3's bound of 2^-20, and walked on the literal
+    divisions as a whole.  A terrain whose heights include 1e-7, -1e-12, 3e-17 and `tiniest`, and whose first column sits at
+    x = 4e-15: with 2^-60 the scene keeps the fast test (its k_shadow runs the four-wide walk, which needs it), with 2^-61 it
+    falls back; either way hits and occlusion equal the oracle's bit for bit — for random rays, for rays grazing the tiny planes from
+    origins a few ulps away from them (the numerator o - b at its smallest) and for rays outside their own guarded range."""
+    from pbrs_amd.spec import SceneBuilder, deg
+    n = 96
+    xs, zs = np.meshgrid(np.linspace(-8.0, 8.0, n + 1), np.linspace(2.0, 18.0, n + 1), indexing="ij")
+    ys = 0.8 * np.sin(0.9 * xs) * np.cos(0.7 * zs)
+    rs = np.random.RandomState(7)
+    tiny = np.array([1e-7, -1e-12, 3e-17, tiniest, -tiniest * 1.5, 7.4e-7, -9.8e-8], dtype=np.float64)
+    for k in range(60):
+        ys[rs.randint(1, n), rs.randint(1, n)] = tiny[k % len(tiny)]
+    xs[n // 2, :] = 4e-15
+    pos = np.stack([xs, ys, zs], axis=-1).reshape(-1, 3).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    v00 = (i * (n + 1) + j).ravel()
+    idx = np.concatenate([np.stack([v00, v00 + 1, v00 + n + 1], axis=-1), np.stack([v00 + n + 1, v00 + 1, v00 + n + 2], axis=-1)]).astype(np.uint32)
+    sb = SceneBuilder()
+    m = sb.lambertian((0.5, 0.5, 0.5))
+    sb.instance(sb.mesh(pos, [(0, 1, 0)] * len(pos), [(0, 0)] * len(pos), idx), m)
+    sb.instance(sb.sphere((0, 3, 10), 0.5), m)
+    sb.set_camera(64, 48, deg(60.0), (0, 6, -4), (0, 0, 10))
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    N = 6000
+    o = np.stack([rs.uniform(-9, 9, N), rs.uniform(-1, 6, N), rs.uniform(0, 20, N)], axis=1).astype(np.float32)
+    d = rs.normal(size=(N, 3)).astype(np.float32)
+    # origins ON and next to the tiny planes: y (or x) a few ulps from a tiny coordinate, or exactly it
+    k = N // 6
+    pick = tiny[rs.randint(0, len(tiny), k)].astype(np.float32)
+    o[:k, 1] = np.where(rs.rand(k) < 0.3, pick, np.nextafter(pick, np.float32(1.0)))
+    d[:k, 1] *= np.float32(1e-3)  # grazing
+    o[k:2 * k, 0] = np.nextafter(np.float32(4e-15), np.float32(0.0))
+    d[2 * k:2 * k + 200, 0] = 0.0            # outside the rays' own range: the literal divisions
+    o[2 * k + 200:2 * k + 400, 2] = 1e-30
+    tmax = np.where(rs.rand(N) < 0.5, np.inf, rs.uniform(1, 30, N)).astype(np.float32)
+    h_ref, occ_ref, st = osc.intersect(o, d, tmax)
+    h_gpu, occ_gpu = gpu_ctx.intersect(o, d, tmax)
+    info = gpu_ctx.last_intersect_info()
+    assert info["wide_any"] == (1 if tiniest >= 2.0 ** -60 else 0), info  # the wide any-hit walk needs the division-free test
+    keep = ~st["tie_mask"]
+    assert_hits_equal(h_ref[keep], h_gpu[keep])
+    assert (occ_ref == occ_gpu).all()
+    assert (h_ref["inst"] != 0xFFFFFFFF).mean() > 0.3 and 0.1 < occ_ref.mean() < 0.9
+    img_ref, _ = osc.render(2, 2, 4, 3)
+    img_gpu, _ = gpu_ctx.render(2, 2, 4, 3)
+    assert (bits(img_ref) == bits(img_gpu)).all()
