@@ -285,7 +285,7 @@ class Workload:
         if os.path.exists(ipath):
             with open(ipath) as f:
                 isa_doc = json.load(f)
-        rep = roofline.stage_report(cst, times, scene_nbytes=self.hs.nbytes, traffic_doc=traffic_doc, isa_doc=isa_doc)
+        rep = roofline.stage_report(cst, times, scene_nbytes=self.hs.nbytes, traffic_doc=traffic_doc, isa_doc=isa_doc, serial_times=serial_times)
         dom_name, dom = roofline.dominant(rep)
         trav = roofline.traversal(rep)
         # the queue/state bytes are a model: a fraction above 1 says the model is off, which the line reports instead of hiding
@@ -338,13 +338,16 @@ class Workload:
                 "queue_state_bytes_per_launch": dom["queue_state_bytes_per_launch"], "scene_miss_bytes_per_launch": dom["scene_miss_bytes_per_launch"],
                 "scene_bytes_per_launch": dom["scene_bytes_per_launch"], "cache_work_rate_GBps": dom["cache_work_rate_GBps"],
                 "ms_per_launch": dom["ms_per_launch"], "launches_per_step": dom["launches"],
+                "ms_per_launch_serial": dom.get("ms_per_launch_serial"), "frac_serial": dom.get("frac_serial"),
                 "bound_shares": roofline.bound_shares(dom),
                 "valu_issue_frac": dom.get("valu_issue_frac"), "valu_issue_frac_min": dom.get("valu_issue_frac_min"),
                 "valu_issue_frac_nominal": dom.get("valu_issue_frac_nominal"), "valu_32bit_encoding_share": dom.get("valu_32bit_encoding_share"),
                 "salu_issue_frac": dom.get("salu_issue_frac"), "valu_lanes_active": dom.get("valu_lanes_active"),
                 "l1_access_frac": dom.get("l1_access_frac"), "l1_accesses_per_launch": dom.get("l1_accesses_per_launch"),
                 "ta_busy_share": dom.get("ta_busy_share"), "td_busy_share": dom.get("td_busy_share"),
-                "note": "rank 0's kernels, the stage with the most time per frame; bound = the resource the kernel fills the largest share of "
+                "note": "rank 0's kernels, the stage with the most exclusive time per frame (stages_ms_serial); ms_per_launch / achieved / frac are measured "
+                        "over the timed frames, where a pass's late bounces share the chip with the next pass's first ones (stages_overlap); "
+                        "ms_per_launch_serial / frac_serial are the same kernel with the overlap off; bound = the resource the kernel fills the largest share of "
                         "(bound_shares, every share <= 1): hbm (measured L2 -> fabric traffic where a counter file applies, else the model), valu_issue, "
                         "salu_issue, l1_access or td_busy (frac stays the HBM fraction); l1_access_frac = L1 accesses per launch (one per lane of "
                         "a load whose lanes name different lines, whatever its width: rocprofv3 TCP_TOTAL_CACHE_ACCESSES, offline) over 256 CUs x "

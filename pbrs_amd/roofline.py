@@ -183,10 +183,12 @@ def static_mix(isa_doc, traffic_doc, kernel):
     return num / den if den else None
 
 
-def stage_report(counters, times, scene_nbytes=0, traffic_doc=None, isa_doc=None):
+def stage_report(counters, times, scene_nbytes=0, traffic_doc=None, isa_doc=None, serial_times=None):
     """counters: stats dict of an instrumented frame; times: per-frame stage times and launch counts of the timed frames;
     scene_nbytes: size of the resident scene; traffic_doc: parsed profiles/latest_traffic_<config>.json or None; isa_doc: parsed
-    profiles/latest_isa_mix.json (static encoding mix per kernel) or None."""
+    profiles/latest_isa_mix.json (static encoding mix per kernel) or None; serial_times: stage times of one frame rendered with the
+    pass overlap off (exclusive times: in the timed frames a stage's event brackets include the time its kernels share the chip with
+    the other stream's) — reported beside the live figures as *_serial, and what `dominant` ranks the stages by."""
     out = {}
     for stage, (kernel, qfn, sfn, ms_key, launch_key) in STAGES.items():
         ms = float(times[ms_key])
@@ -214,6 +216,10 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None, isa_doc=None
             "cache_work_rate_GBps": ((q + sc) / sec / 1e9) if sec > 0 else 0.0,  # not an HBM figure: may exceed the HBM peak
         }
         out[stage]["frac"] = out[stage]["achieved_GBps"] / HBM_PEAK_GBS
+        if serial_times and serial_times.get(ms_key):
+            ssec = float(serial_times[ms_key]) / launches * 1e-3
+            out[stage]["ms_per_launch_serial"] = float(serial_times[ms_key]) / launches
+            out[stage]["frac_serial"] = (q + miss) / ssec / 1e9 / HBM_PEAK_GBS
         # what the counters saw (L2 -> fabric requests, Infinity-Cache hits included), beside the model
         out[stage]["frac_measured"] = (traffic / sec / 1e9 / HBM_PEAK_GBS) if (traffic is not None and sec > 0) else None
         valu = kernel_valu(traffic_doc, kernel, launches)
@@ -249,7 +255,8 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None, isa_doc=None
 
 
 def dominant(report):
-    return max(report.items(), key=lambda kv: kv[1]["ms_per_launch"] * kv[1]["launches"])
+    """The stage with the most time per frame: by exclusive (serial) time where the report has it, else by the live brackets."""
+    return max(report.items(), key=lambda kv: kv[1].get("ms_per_launch_serial", kv[1]["ms_per_launch"]) * kv[1]["launches"])
 
 
 def traversal(report):

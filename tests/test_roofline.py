@@ -129,3 +129,16 @@ def test_l1_access_share_from_the_tcp_pass():
     assert e["td_busy_share"] == 0.8 and e["ta_busy_share"] == 0.6
     assert roofline.bound_of(e) == "l1_access"
     assert "l1_access_frac" not in rep["shadow"]
+
+
+def test_stages_are_ranked_by_exclusive_time_when_a_serial_frame_is_given():
+    """With the pass overlap a stage's live event brackets include the time its kernels share the chip with the other stream's: the
+    dominant stage is chosen by the exclusive times of a frame rendered with the overlap off, reported beside the live figures."""
+    live = dict(TIMES, ms_shade=TIMES["ms_extend"] * 3.0)  # late-stream brackets stretched by the next pass's kernels
+    serial = {"ms_extend": TIMES["ms_extend"], "ms_shade": TIMES["ms_extend"] * 0.2, "ms_shadow": TIMES["ms_extend"] * 0.5}
+    rep = roofline.stage_report(COUNTS, live, scene_nbytes=1 << 30, serial_times=serial)
+    assert roofline.dominant(rep)[0] == "extend"
+    assert roofline.dominant(roofline.stage_report(COUNTS, live, scene_nbytes=1 << 30))[0] == "shade"
+    e = rep["extend"]
+    assert e["ms_per_launch_serial"] == serial["ms_extend"] / e["launches"] and abs(e["frac_serial"] - e["frac"]) < 1e-12
+    assert rep["shade"]["frac_serial"] > rep["shade"]["frac"]
