@@ -232,14 +232,12 @@ class Workload:
 
         # Untimed: one frame with every pass on one stream, for per-stage milliseconds that are exclusive times (in the timed frames a pass's
         # late bounces run on a second stream beside the next pass's first bounces: their event brackets overlap and do not add up)
-        serial_times = None
-        if self.my_rows:
-            self.ctx.set_pass_overlap(False)
-            try:
-                _, (sst,) = self.frames(1, timing=True)
-            finally:
-                self.ctx.set_pass_overlap(True)
-            serial_times = {k: v for k, v in sst.items() if k.startswith("ms_")}
+        self.ctx.set_pass_overlap(False)
+        try:
+            _, (sst,) = self.frames(1, timing=True)  # (every rank: the frame hand-over is collective)
+        finally:
+            self.ctx.set_pass_overlap(True)
+        serial_times = {k: v for k, v in sst.items() if k.startswith("ms_")} if sst else None
         # Untimed: instrumented frame for ray / node / primitive counts (deterministic, equal to the timed work).
         frame, (cst,) = self.frames(1, counters=True)
         nb = 16
