@@ -74,6 +74,19 @@ PD float4 pack4(f3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_
 PD float4 pack4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 PD f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
 #define PBRS_SLOT_MASK 0x3fffffffu
+// Queue and state records are streams: written by one kernel, read once by the next, tens of GB apart.  k_shade's and k_raygen's record
+// traffic and k_extend's hit store are marked non-temporal, so that they do not push scene data out of the L2 (C4 +0.7 %, C2 +0.6 %, C3
+// +1 %, c4xl +0.7 % in same-box A/B: profiles/r04r_ab_nontemporal_streams.log).  The rays a traversal kernel fetches stay ordinary loads:
+// a walk reads its ray record again when it leaves an instance (traverse.h, reload_world).
+PD float4 ld_stream(const float4* p) {
+    const pbrs_f4v v = __builtin_nontemporal_load(reinterpret_cast<const pbrs_f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+PD void st_stream(float4* p, float4 v) {
+    pbrs_f4v w;
+    w.x = v.x, w.y = v.y, w.z = v.z, w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<pbrs_f4v*>(p));
+}
 
 // ---- slot order of a pass ----------------------------------------------------------------------------------------
 // The P * K camera samples of a pass, in queue order: the pixels are cut into chunks of C (RenderConst::chunk_pixels; the
@@ -132,10 +145,10 @@ __global__ void __launch_bounds__(256) k_raygen(PathState st, RenderConst rc) {
     float y = (float)row + pn_fract(jy);
     f3 dir = ld3(rc.cam.c) + ld3(rc.cam.a) * x + ld3(rc.cam.b) * y;
     // bounce 0: the queue position of a path is its slot
-    st.q[0][0][slot] = pack4(ld3(rc.cam.center), slot);
-    st.q[0][1][slot] = pack4(dir, (uint32_t)rng);
-    st.q[0][2][slot] = pack4(gray(1.0f), (uint32_t)(rng >> 32));
-    st.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    st_stream(&st.q[0][0][slot], pack4(ld3(rc.cam.center), slot));
+    st_stream(&st.q[0][1][slot], pack4(dir, (uint32_t)rng));
+    st_stream(&st.q[0][2][slot], pack4(gray(1.0f), (uint32_t)(rng >> 32)));
+    st_stream(&st.L[slot], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 }
 
 struct GlobalCounters {  // instrumented variant only
@@ -465,7 +478,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                         cls = (specular || ((split & 2u) && S.has_env != 0u)) ? 1u : 0u;
                     }
                 }
-                if (!split || cls) st.hit[item] = make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), __uint_as_float(split ? 0u : cls));
+                if (!split || cls) st_stream(&st.hit[item], make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), __uint_as_float(split ? 0u : cls)));
                 if (S.n_classes > 1u || split) st.cls[item] = (uint8_t)cls;  // what the class sort reads: 1 byte per path instead of a 16-byte record
                 walk.mode = PBRS_WALK_IDLE;
             }
@@ -610,7 +623,7 @@ __global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : 
         // several shading classes: lanes take the paths in class order (k_class_sort), so that a wave runs one material's code; a
         // queue k_extend split into kept and dropped paths: lanes take the kept positions (class 1 of a class-major order)
         const uint32_t src = sorted ? st.perm[i] : i;
-        const float4 r0 = st.q[set][0][src], r1 = st.q[set][1][src], r2 = st.q[set][2][src], rh = st.hit[src];
+        const float4 r0 = ld_stream(&st.q[set][0][src]), r1 = ld_stream(&st.q[set][1][src]), r2 = ld_stream(&st.q[set][2][src]), rh = ld_stream(&st.hit[src]);
         slot = __float_as_uint(r0.w) & PBRS_SLOT_MASK;
         const float4 rl = st.L[slot];
         f3 o = xyz(r0), d = xyz(r1);
@@ -971,22 +984,22 @@ __global__ void __launch_bounds__(256, (SPEC & 8u) ? PBRS_FOURIER_SHADE_WAVES : 
     }
     if (alive) {
         const uint32_t j = b_alive + lane_prefix(m_alive), out = (bounce + 1u) & 1u;
-        st.q[out][0][j] = pack4(next_o, slot | next_spec);
-        st.q[out][1][j] = pack4(next_d, (uint32_t)next_rng);
-        st.q[out][2][j] = pack4(next_beta, (uint32_t)(next_rng >> 32));
+        st_stream(&st.q[out][0][j], pack4(next_o, slot | next_spec));
+        st_stream(&st.q[out][1][j], pack4(next_d, (uint32_t)next_rng));
+        st_stream(&st.q[out][2][j], pack4(next_beta, (uint32_t)(next_rng >> 32)));
     }
     if (both) nee_queue[b_nee + lane_prefix(m_nee)] = slot;
     if (cast0) {
         const size_t j = (size_t)b_sh + lane_prefix(m_c0);
-        st.sr[0][j] = pack4(sr0.o, sr0.t_max);
-        st.sr[1][j] = pack4(sr0.d, slot | lone);
-        if (lone) st.sr[2][j] = pack4(L_vis, 0.0f);
+        st_stream(&st.sr[0][j], pack4(sr0.o, sr0.t_max));
+        st_stream(&st.sr[1][j], pack4(sr0.d, slot | lone));
+        if (lone) st_stream(&st.sr[2][j], pack4(L_vis, 0.0f));
     }
     if (cast1) {
         const size_t j = (size_t)b_sh + s_cnt[wave][2] + lane_prefix(m_c1);
-        st.sr[0][j] = pack4(sr1.o, sr1.t_max);
-        st.sr[1][j] = pack4(sr1.d, slot | 0x80000000u | lone);
-        if (lone) st.sr[2][j] = pack4(L_vis, 0.0f);
+        st_stream(&st.sr[0][j], pack4(sr1.o, sr1.t_max));
+        st_stream(&st.sr[1][j], pack4(sr1.d, slot | 0x80000000u | lone));
+        if (lone) st_stream(&st.sr[2][j], pack4(L_vis, 0.0f));
     }
 #ifdef PBRS_PROBE_SHADE
     PBRS_SHADE_MARK(7);  // compaction + queue / record writes
