@@ -750,12 +750,15 @@ int render_common(pbrs_ctx* c, const pbrs_camera* cam, const pbrs_render_params*
     // stream: those are near-empty launches that end with the latency of their longest walks (C4: 47 ms per frame in kernels that leave
     // most of the chip idle, profiles/r04k_trace_gaps_c4.log) — the next pass's first bounces, queued behind the hand-over on the main
     // stream, fill it.  The instrumented render keeps one stream (its counters are per pass).
-    const bool two = c->overlap_passes && !stats && spp > K;
+    bool two = c->overlap_passes && !stats && spp > K;
     if (two) {
         use_pass_set(c, 1);
         rcode = ensure_work(c, (size_t)P * K, P);
         use_pass_set(c, 0);
-        if (rcode) return rcode;
+        if (rcode) {  // no memory for the second set (a device shared with other processes): every pass on the main stream, as before
+            two = false;
+            c->error.clear();
+        }
     }
     for (uint32_t first = 0; first < spp; first += K) {
         uint32_t kc = spp - first < K ? spp - first : K;

@@ -138,3 +138,34 @@ def test_n_threads_n_contexts_assemble_the_single_context_frame(n_threads):
     assert max(t["bands"] for t in rep["threads"]) - min(t["bands"] for t in rep["threads"]) <= 1
     assert abs(rep["band_imbalance"] - max(rows) / (136 / n_threads)) < 1e-9
     assert all(t["gpu_ms"] > 0 for t in rep["threads"])
+
+
+def test_a_callers_stream_orders_the_overlapped_passes():
+    """pbrs_set_stream: the pipeline runs in the order of a stream the host owns (here one of torch's).  With several passes a pass's
+    late bounces run on the context's second stream — forked from and joined back into the caller's stream by events — so work the
+    caller queues on ITS stream after pbrs_render_tile_device (a device-to-host copy, no pbrs_collect_stats) sees the finished
+    frame; two such frames back to back, then the context's own stream again."""
+    import torch
+    sb, c = scenes.build_config("c3", width=128, height=96)
+    hs = pbrs_amd.HostScene(sb)
+    ref, _ = OracleScene(sb).render(3, 3, c["depth"], 31)
+    ctx = pbrs_amd.Context(0)
+    try:
+        ctx.upload(hs)
+        stream = torch.cuda.Stream(device="cuda:0")
+        ctx.set_stream(stream.cuda_stream)
+        dev = torch.zeros((96, 128, 3), dtype=torch.float32, device="cuda:0")
+        host = [torch.empty((96, 128, 3), dtype=torch.float32).pin_memory() for _ in range(2)]
+        with torch.cuda.stream(stream):
+            for k in range(2):
+                ctx.render_device(dev.data_ptr(), 3, 3, c["depth"], 31, samples_per_pass=2)  # five passes, overlapped
+                host[k].copy_(dev, non_blocking=True)  # ordered after the frame by the stream alone
+                dev.zero_()                            # ... and before the next frame's writes
+        stream.synchronize()
+        for k in range(2):
+            assert (bits(host[k].numpy()) == bits(ref)).all(), k
+        ctx.set_stream(0)
+        img, _ = ctx.render(3, 3, c["depth"], 31, samples_per_pass=2)
+        assert (bits(img) == bits(ref)).all()
+    finally:
+        ctx.close()
