@@ -445,14 +445,14 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
     PBRS_TT_DECL;
-    uint32_t item = 0;  // queue position of the lane's ray
+    uint32_t item = 0;  // queue position of the lane's ray; bit 31: the path record's "after a specular bounce" flag (queues stay below 2^28)
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
         if ((uint32_t)__popcll(live) < S.refill_below) {
             PBRS_KP_WAVE(1);
             if constexpr (WIDE) {
-                wave_append_slow(walk.mode == PBRS_WALK_SLOW, item, slow_list, slow_count);
+                wave_append_slow(walk.mode == PBRS_WALK_SLOW, item & 0x7fffffffu, slow_list, slow_count);
                 if (walk.mode == PBRS_WALK_SLOW) walk.mode = PBRS_WALK_IDLE;
             }
             if (walk.mode == PBRS_WALK_DONE) {  // finished walks are retired in batches, at refill time
@@ -474,12 +474,15 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                     // specular bounce under a black environment beta may be infinite: beta * 0 is kept for k_shade to add.)
                     cls = 1u;
                     if (h.inst == 0xffffffffu) {
-                        const bool specular = (__float_as_uint(q0[item].w) >> 31) != 0u;  // the path record's flag, read again: misses only
+                        // (the path record's flag rides in `item` since the ray was fetched: reading the record again here put a
+                        // memory round trip into every refill of an open scene)
+                        const bool specular = (item >> 31) != 0u;
                         cls = (specular || ((split & 2u) && S.has_env != 0u)) ? 1u : 0u;
                     }
                 }
-                if (!split || cls) st_stream(&st.hit[item], make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), __uint_as_float(split ? 0u : cls)));
-                if (S.n_classes > 1u || split) st.cls[item] = (uint8_t)cls;  // what the class sort reads: 1 byte per path instead of a 16-byte record
+                const uint32_t pos = item & 0x7fffffffu;
+                if (!split || cls) st_stream(&st.hit[pos], make_float4(h.t, __uint_as_float(h.inst), __uint_as_float(h.prim), __uint_as_float(split ? 0u : cls)));
+                if (S.n_classes > 1u || split) st.cls[pos] = (uint8_t)cls;  // what the class sort reads: 1 byte per path instead of a 16-byte record
                 walk.mode = PBRS_WALK_IDLE;
             }
             if (work.left()) {
@@ -488,7 +491,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                     if (indirect) idx = indirect[idx];
                     stk.item = idx;
                     const float4 a = q0[idx], b = q1[idx];
-                    item = idx;
+                    item = idx | (__float_as_uint(a.w) & 0x80000000u);
                     walk.start(S, xyz(a), xyz(b), pn_inf(), stk);
                     nrays++;
                     PBRS_KP_LANE(2, true);
@@ -1186,6 +1189,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
     PBRS_KP_DECL(walk);
     PBRS_TT_DECL;
     uint32_t item = 0, rec = 0;
+    f3 l_vis = gray(0.0f);  // a lone ray's "unoccluded" outcome, fetched with the ray: read at retire time it put a memory round trip into every refill
     WaveWork work = wave_work_init(n);
     for (;;) {
         uint64_t live = __ballot(walk.mode == PBRS_WALK_NODE || walk.mode == PBRS_WALK_LEAF || walk.mode == PBRS_WALK_XFER);
@@ -1201,11 +1205,10 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                 if (item & 0x40000000u) {
                     // the path's only shadow ray: k_shade stored the occluded outcome in L and sent the other one along
                     if (!occluded) {
-                        const float4 lv = st.sr[2][rec];
                         float* l = reinterpret_cast<float*>(st.L + slot);  // .w (the direct integrator's 1 / mass) stays
-                        l[0] = lv.x;
-                        l[1] = lv.y;
-                        l[2] = lv.z;
+                        l[0] = l_vis.x;
+                        l[1] = l_vis.y;
+                        l[2] = l_vis.z;
                     }
                 } else {
                     at(st.occ[r], slot) = occluded ? 1 : 0;
@@ -1220,6 +1223,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
                     stk.item = idx;
                     const float4 q0 = st.sr[0][idx], q1 = st.sr[1][idx];
                     item = __float_as_uint(q1.w);
+                    if (item & 0x40000000u) l_vis = xyz(st.sr[2][idx]);
                     walk.start(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, stk);
                     nrays++;
                     PBRS_KP_LANE(2, true);
