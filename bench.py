@@ -345,7 +345,8 @@ class Workload:
                 "ta_busy_share": dom.get("ta_busy_share"), "td_busy_share": dom.get("td_busy_share"),
                 "note": "rank 0's kernels, the stage with the most exclusive time per frame (stages_ms_serial); ms_per_launch / achieved / frac are measured "
                         "over the timed frames, where a pass's late bounces share the chip with the next pass's first ones (stages_overlap); "
-                        "ms_per_launch_serial / frac_serial are the same kernel with the overlap off; bound = the resource the kernel fills the largest share of "
+                        "ms_per_launch_serial / frac_serial are the same kernel with the overlap off, and the shares that divide offline per-launch "
+                        "counters by a time (frac_measured, valu / salu_issue_frac, l1_access_frac) divide by that exclusive time; bound = the resource the kernel fills the largest share of "
                         "(bound_shares, every share <= 1): hbm (measured L2 -> fabric traffic where a counter file applies, else the model), valu_issue, "
                         "salu_issue, l1_access or td_busy (frac stays the HBM fraction); l1_access_frac = L1 accesses per launch (one per lane of "
                         "a load whose lanes name different lines, whatever its width: rocprofv3 TCP_TOTAL_CACHE_ACCESSES, offline) over 256 CUs x "

@@ -203,6 +203,10 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None, isa_doc=None
         else:
             miss, miss_src = min(max(traffic - q, 0.0), sc), "measured traffic - queue/state bytes, capped at the scene bytes"
         sec = ms / launches * 1e-3
+        # The issue / L1 / measured-traffic shares below divide offline per-launch counters by a per-launch time: the exclusive time of a
+        # frame rendered with the pass overlap off where the caller has one (in the timed frames a late-bounce launch shares the chip with
+        # the next pass's kernels, and its bracket is the longer for it), else the live one.  `frac` stays on the live time.
+        xsec = (float(serial_times[ms_key]) / launches * 1e-3) if (serial_times and serial_times.get(ms_key)) else sec
         out[stage] = {
             "kernel": kernel,
             "launches": launches,
@@ -221,8 +225,9 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None, isa_doc=None
             out[stage]["ms_per_launch_serial"] = float(serial_times[ms_key]) / launches
             out[stage]["frac_serial"] = (q + miss) / ssec / 1e9 / HBM_PEAK_GBS
         # what the counters saw (L2 -> fabric requests, Infinity-Cache hits included), beside the model
-        out[stage]["frac_measured"] = (traffic / sec / 1e9 / HBM_PEAK_GBS) if (traffic is not None and sec > 0) else None
+        out[stage]["frac_measured"] = (traffic / xsec / 1e9 / HBM_PEAK_GBS) if (traffic is not None and xsec > 0) else None
         valu = kernel_valu(traffic_doc, kernel, launches)
+        sec = xsec
         if valu and sec > 0:
             # share of the chip's vector issue slots the kernel fills (instruction counts measured offline, time live): what
             # binds the kernels that HBM does not — a lower bound, the sustained clock being below CLOCK_HZ

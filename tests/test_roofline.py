@@ -142,3 +142,17 @@ def test_stages_are_ranked_by_exclusive_time_when_a_serial_frame_is_given():
     e = rep["extend"]
     assert e["ms_per_launch_serial"] == serial["ms_extend"] / e["launches"] and abs(e["frac_serial"] - e["frac"]) < 1e-12
     assert rep["shade"]["frac_serial"] > rep["shade"]["frac"]
+
+
+def test_offline_counter_shares_divide_by_the_exclusive_time():
+    """Counters per launch come from offline passes; the time they are divided by is the exclusive per-launch time of the serial frame
+    where there is one (a late-bounce launch's live bracket includes the time it shares the chip with the next pass's kernels)."""
+    doc = {"geometry": {"frames": 1}, "kernels": {"k_shade<0u, false, 101u>": {"launches": 2, "l2_fabric_total": 8.0e6, "valu_insts": 2.0e8, "valu_lanes_active": 60.0,
+                                                                                   "l1_accesses": 1.0e8, "salu_insts": 1.0e7}}}
+    live = dict(TIMES, ms_shade=TIMES["ms_shade"] * 2.5)
+    serial = {"ms_extend": TIMES["ms_extend"], "ms_shade": TIMES["ms_shade"], "ms_shadow": TIMES["ms_shadow"]}
+    a = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30, traffic_doc=doc)["shade"]
+    b = roofline.stage_report(COUNTS, live, scene_nbytes=1 << 30, traffic_doc=doc, serial_times=serial)["shade"]
+    for key in ("valu_issue_frac", "salu_issue_frac", "l1_access_frac", "frac_measured"):
+        assert abs(a[key] - b[key]) < 1e-12, key
+    assert abs(b["frac"] * 2.5 - a["frac"]) < 1e-12 and abs(b["frac_serial"] - a["frac"]) < 1e-12
