@@ -270,7 +270,8 @@ typedef struct pbrs_stats {
     uint32_t launches_extend, launches_shadow, launches_shade, passes;
     /* Which instantiation of the traversal kernels the render's passes launched (always filled): bit 0 analytic shapes, 1 per-candidate
      * shading check, 2 scanned TLAS, 3 several node steps per round (deep BLAS), 4 walks over four-wide nodes, 5 full further node
-     * steps (a scene with coordinates outside the guarded range of the division-free box test), 6 scene arrays staged in LDS, 7 an unscanned TLAS staged in LDS;
+     * steps (a scene with coordinates outside the guarded range of the division-free box test), 6 scene arrays staged in LDS, 7 an unscanned TLAS staged in LDS,
+     * 8 (k_extend) the TLAS extent follows the reference's ray.t_max to the letter, rises included (a ParallelQuad next to a mesh);
      * 0x80000000: the instrumented variant (collect_counters). */
     uint32_t kernel_features_extend, kernel_features_shadow;
     /* Queue sizes per bounce, summed over the passes of the render (filled with the work counters): paths_at_bounce[b] = rays

@@ -363,7 +363,7 @@ struct ClosestSel {
 };
 template <bool STATS, uint32_t FEAT>
 struct ClosestSel<0u, STATS, FEAT> {
-    typedef ClosestWalk<STATS, (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_LDS_TOP))> type;
+    typedef ClosestWalk<STATS, (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_LDS_TOP | PBRS_FEAT_EXTENT))> type;
 };
 template <uint32_t ARITY, bool STATS, uint32_t FEAT>
 struct AnySel {
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(256, STATS ? 3 : (FEAT & PBRS_FEAT_WIDE) ? PBR
     Cnt<STATS> cnt;
     cnt.init();
     uint32_t nrays = 0, nhit = 0;
-    typename ClosestSel<ARITY, STATS, (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_LDS_TOP))>::type walk;
+    typename ClosestSel<ARITY, STATS, (FEAT & (PBRS_FEAT_ALL | PBRS_FEAT_LDS_TOP | PBRS_FEAT_EXTENT))>::type walk;
     walk.mode = PBRS_WALK_IDLE;
     PBRS_KP_DECL(walk);
     PBRS_TT_DECL;
@@ -1345,7 +1345,8 @@ __global__ void __launch_bounds__(256) k_intersect_rays(DevScene S, uint32_t n, 
             if constexpr (WIDE_CLOSEST) tlas_closest_wide(S, active, o, d, t_max, stk, h, slow);
             else
 #endif
-                tlas_closest<false>(S, active, o, d, t_max, stk, h, cnt);
+            if (S.exact_extent) tlas_closest<false, PBRS_FEAT_EXTENT>(S, active, o, d, t_max, stk, h, cnt);  // as the scene's k_extend
+            else tlas_closest<false>(S, active, o, d, t_max, stk, h, cnt);
             if (active) {
                 pbrs_hit_record r;
                 r.t = h.t;

@@ -30,6 +30,7 @@ struct DevScene {
     float env[3];
     uint32_t has_env;
     uint32_t fast_slab;  // node coordinates are inside the range the division-free box test is exact for (traverse.h)
+    uint32_t exact_extent;  // a ParallelQuad instance (hits outside its own box, D1) next to a mesh (hits beyond the extent it was given): the closest-hit walks take PBRS_FEAT_EXTENT
     // Small TLAS (PBRS_FLAT_TLAS_MIN..MAX instances): its leaves alone, in pre-order = the order the tree walk reaches them.
     // A box inside a box that a ray misses is missed too (each slab bound is a correctly rounded, hence monotonic,
     // function of the box coordinate), so testing the leaf boxes in this order — each against the t_max of its turn —
@@ -77,6 +78,8 @@ struct DevScene {
 #define PBRS_FEAT_SHADING_CHECK 2u  // some mesh needs the tangent check of blas.rs:193-200 evaluated per candidate hit
 #define PBRS_FEAT_FLAT_TLAS 4u      // the leaf copies at DevScene::flat_off are built: rays on the division-free box test scan the TLAS leaves
 #define PBRS_FEAT_ALL 7u
+#define PBRS_FEAT_EXTENT 256u        // closest-hit walk only, outside the kernel tables: the TLAS extent is the reference's ray.t_max to the letter, rises included
+                                    // (traverse.h, ClosestWalk::EXT): scenes with a ParallelQuad next to a mesh (pbrs_upload_scene)
 #define PBRS_FEAT_LONG_WALKS 8u     // kernels only (not a property of the walks): several node steps per loop round (kernels.h)
 #define PBRS_FEAT_WIDE 16u          // kernels only: the walks over four-wide nodes (device/wide.h); needs PBRS_FEAT_FLAT_TLAS
 #define PBRS_FEAT_LDS_TOP 128u      // kernels only: the head of DevScene::nodes — a TLAS too large to scan — is copied into the block's LDS (scenes whose arrays do not fit as a whole)

@@ -166,8 +166,9 @@ PD uint32_t enter_instance(const DevScene& S, const pbrs_instance& in, uint32_t 
 //    children pushed far-then-near by `ray.dir[axis] > 0` (blas.rs:456-466); within a leaf the
 //    triangles see the t_max from before the leaf and `new.t < outer.t` keeps the first of equals.
 //  * the mesh may return a hit beyond the incoming extent (it loses at the TLAS compare).
-// Known deviation: ray.t_max is never RAISED by such an overshoot; observable only on
-// bit-identical t from two instances (oracle counter tlas_ties).
+// Known deviation: outside PBRS_FEAT_EXTENT (below) ray.t_max is never RAISED by such an overshoot; observable
+// on bit-identical t from two instances (oracle counter tlas_ties) — and where a shape reports hits outside its own box
+// (ParallelQuad, D1), which is why scenes with one next to a mesh walk with PBRS_FEAT_EXTENT (fuzz seed 211699, round 4).
 // Walk states.  A kernel advances every lane by single steps — one node (pop + box test) or one primitive — so that
 // lanes of one wave that are in different phases of their walks still share the instruction stream (k_extend).
 #ifndef PBRS_EARLY_OUT  // a failed box test that leaves nothing pending below the instance goes to the boundary state at once
@@ -385,10 +386,22 @@ struct ClosestWalk {
     uint32_t cand;        // leaves of the leaf copies at DevScene::flat_off still to visit: their boxes passed the shared scan (0 on a tree walk)
     bool in_blas, moved;  // moved: C is not the world ray (inst_info bit 30: only its origin differs)
     uint32_t mode;
+    // PBRS_FEAT_EXTENT: t_max is the reference's ray.t_max to the letter.  bvh.rs:84-88 sets it to the LEFT subtree's result when
+    // that subtree returns one — not to the best hit so far: a mesh may return a hit beyond the extent it was given (blas.rs:468), the
+    // extent then RISES, and boxes the best hit would have pruned are entered.  What they hold loses at the compare (bvh.rs:94-98)
+    // unless a shape reports hits outside its own box, which ParallelQuad does (D1, the mirrored quadrants): scenes with such an
+    // instance next to a mesh take this walk (pbrs_upload_scene).  A pending right sibling carries, in a second stack word, the
+    // smallest t returned since the window of the entry below it began; `win` is that of the innermost window.  When the sibling is
+    // popped its left subtree is complete: win is the left result (set_extent), and folds into the window below.
+    static constexpr bool EXT = (FEAT & PBRS_FEAT_EXTENT) != 0u;
+    float win;
+    bool win_has;
     PBRS_TP_FIELDS
 
     PD void start(const DevScene& S, f3 o, f3 d, float tmax, LaneStack stk) {
         C = make_space(o, d, S.fast_slab != 0);
+        win = 0.0f;
+        win_has = false;
         moved = false;
         best.t = pn_inf();
         best.inst = 0xffffffffu;
@@ -402,7 +415,7 @@ struct ClosestWalk {
         mb1 = mb2 = 0.0f;
         blas_base = 0;
         cand = 0;
-        if ((FEAT & PBRS_FEAT_FLAT_TLAS) && S.n_flat != 0u && C.fast) {
+        if ((FEAT & PBRS_FEAT_FLAT_TLAS) && !EXT && S.n_flat != 0u && C.fast) {  // (the extent's windows follow the tree)
             sp = 0;
             mode = PBRS_WALK_SCAN;
         } else {
@@ -417,7 +430,7 @@ struct ClosestWalk {
     // filter runs with an infinite extent — a box the ray misses at any distance — because t_max does not only come down:
     // a mesh may return a hit beyond the extent it was given (blas.rs:468) and `set_extent` then raises it (bvh.rs:84-88).
     PD void scan_wave(const DevScene& S, Cnt<STATS>& cnt) {
-        if (!(FEAT & PBRS_FEAT_FLAT_TLAS)) return;
+        if (!(FEAT & PBRS_FEAT_FLAT_TLAS) || EXT) return;
         uint32_t tested = 0;
 #ifdef PBRS_EXACT_CLOSEST_SCAN
         const uint32_t mine = FlatScan::run(S, mode == PBRS_WALK_SCAN, C, pn_inf(), tested);
@@ -450,6 +463,19 @@ struct ClosestWalk {
             cand &= cand - 1u;
         } else {
             ni = stk.get(--sp);
+            if constexpr (EXT) {
+                if (!in_blas && (ni & 0x80000000u)) {  // a right sibling: its left subtree has returned (bvh.rs:84-88)
+                    const bool below_has = (ni & 0x40000000u) != 0u;
+                    const float below = __uint_as_float(stk.get(--sp));
+                    ni &= 0x3fffffffu;
+                    if (win_has) t_max = win;  // ray.set_extent(isect.ray_t): down or UP
+                    // the window of the entry below goes on: what it held before this subtree, then this subtree's result
+                    // (`l.ray_t < r.ray_t ? l : r`, :94-98: the earlier one only if strictly nearer)
+                    if (below_has && (!win_has || below < win)) win = below;
+                    win_has = win_has || below_has;
+                    lt = t_max;
+                }
+            }
             if (STATS) {  // the scanned leaves were counted by the scan
                 if (in_blas) CNT(blas_nodes);
                 else CNT(tlas_nodes);
@@ -467,6 +493,13 @@ struct ClosestWalk {
             // (blas.rs:456-466), and the cloned ray's t_max follows outer_hit (blas.rs:468).
             bool left_first = !in_blas || comp(C.d, (int)(node.b & 3u)) > 0.0f;
             uint32_t left = ni + 1, right = node.a;
+            if constexpr (EXT) {
+                if (!in_blas) {  // a new window opens for the left subtree; the one it interrupts waits with the right sibling
+                    stk.put(sp++, __float_as_uint(win));
+                    right |= 0x80000000u | (win_has ? 0x40000000u : 0u);
+                    win_has = false;
+                }
+            }
             stk.put(sp++, left_first ? right : left);
             stk.put(sp++, left_first ? left : right);
             lt = in_blas ? mt : lt;
@@ -490,6 +523,7 @@ struct ClosestWalk {
     // second and third copies of the step carry a third fewer scalar instructions (exec-mask bookkeeping of branches that nearly
     // every execution took for one or two lanes).
     PD void node_step_fast(const DevScene& S, LaneStack stk, Cnt<STATS>& cnt) {
+        if constexpr (EXT) return;  // (two-word TLAS entries: node_step's)
         if (sp == (in_blas ? blas_base : 0) || !C.fast) return;  // (a ray on the literal divisions: the first step's, too)
         PBRS_TP(0);
         const uint32_t ni = stk.get(--sp);
@@ -534,13 +568,17 @@ struct ClosestWalk {
         // (x / 0 with an infinite extent), so those are flagged
         if (mt < pn_inf() || (inst_info & 0x80000000u)) {
             CNT(instance_hits);
+            if constexpr (EXT) {  // every returned hit counts for the windows, the best one or not
+                if (!win_has || !(win < mt)) win = mt;
+                win_has = true;
+            }
             if (!(best.t < mt)) {
                 best.t = mt;
                 best.inst = cur_inst;
                 best.prim = mprim;
                 best.b1 = mb1;
                 best.b2 = mb2;
-                t_max = mt;
+                if constexpr (!EXT) t_max = mt;  // (EXT: when the subtree this leaf is in returns to a node it is the left child of)
             }
         }
     }
@@ -1126,9 +1164,9 @@ struct AnyWalkW : AnyWalk<false, FEAT> {
 
 // One ray per lane start to finish (parity harness; the pipeline kernels interleave walks and refill lanes instead).
 // Every lane of the wave calls these together (leaf_wave); `active` = the lane has a ray.
-template <bool STATS>
+template <bool STATS, uint32_t EXTRA = 0u>  // EXTRA: PBRS_FEAT_EXTENT for the scenes whose pipeline walks with it
 PD void tlas_closest(const DevScene& S, bool active, f3 o, f3 d, float t_max, LaneStack stk, Hit& best, Cnt<STATS>& cnt) {
-    ClosestWalk<STATS, PBRS_FEAT_ALL> w;
+    ClosestWalk<STATS, PBRS_FEAT_ALL | EXTRA> w;
     w.start(S, o, d, t_max, stk);
     if (!active) w.mode = PBRS_WALK_DONE;
     w.scan_wave(S, cnt);

@@ -483,6 +483,15 @@ int launch_extend(pbrs_ctx* c, bool stats, bool wide, uint32_t grid, size_t lds,
     // k_shadow alone, and the instrumented variant, which carries every feature, must then walk the tree like the timed one
     DevScene S = c->S;
     if (!(S.features & PBRS_FEAT_FLAT_TLAS)) S.n_flat = 0u;
+    if (S.exact_extent) {  // the extent follows the tree: no leaf scan, no staging, one kernel each way (scenes with a ParallelQuad: no benchmark holds one)
+        constexpr uint32_t kF = PBRS_FEAT_ANALYTIC | PBRS_FEAT_SHADING_CHECK | PBRS_FEAT_EXTENT;
+        if (stats)
+            hipLaunchKernelGGL((k_extend<true, kF>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt, indirect, slow_list, slow_count, split);
+        else
+            hipLaunchKernelGGL((k_extend<false, kF>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt, indirect, slow_list, slow_count, split);
+        c->pending.kernel_features_extend = kF | (stats ? 0x80000000u : 0u);
+        return PBRS_OK;
+    }
     if (stats) {
         hipLaunchKernelGGL((k_extend<true, PBRS_FEAT_ALL>), dim3(grid), dim3(kBlock), lds, c->stream, S, c->st, set, count, n_direct, heads, c->gcnt, indirect, slow_list,
                            slow_count, split);
@@ -1095,6 +1104,17 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
     for (uint32_t i = 0; i < d->n_instances; ++i)
         if (d->instances[i].shape_kind == PBRS_SHAPE_MESH) max_blas_height = std::max(max_blas_height, bh[d->instances[i].blas_root]);
     uint32_t depth = std::max(tlas_levels, tlas_levels - 1u + max_blas_height);
+    // A ParallelQuad reports hits in the mirrored quadrants of its plane, outside its own box (D1); a mesh may return a hit beyond the
+    // extent it was given, which RAISES ray.t_max when its subtree is a left one (bvh.rs:84-88).  Together they make the rise visible
+    // (a box the best hit would have pruned is entered and holds a nearer hit: fuzz seed 211699), so the closest-hit walks of such a
+    // scene follow ray.t_max to the letter (PBRS_FEAT_EXTENT): a pending TLAS entry then takes two stack words.
+    bool has_quad = false, has_mesh = false;
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+        has_quad = has_quad || d->instances[i].shape_kind == PBRS_SHAPE_QUAD;
+        has_mesh = has_mesh || d->instances[i].shape_kind == PBRS_SHAPE_MESH;
+    }
+    const bool exact_extent = has_quad && has_mesh;
+    if (exact_extent) depth += tlas_levels + 1u;
     if ((size_t)depth * kBlock * sizeof(uint32_t) > kLdsBytesPerCU / 2) return fail(c, PBRS_E_LIMIT, "traversal stack exceeds the LDS budget");
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->second_stream);
@@ -1121,6 +1141,7 @@ int pbrs_upload_scene(pbrs_ctx* c, const pbrs_scene_desc* d) {
             for (int a = 0; a < 3; ++a) ok = ok && coord_ok(d->blas_nodes[i].min[a]) && coord_ok(d->blas_nodes[i].max[a]);
         S.fast_slab = ok ? 1u : 0u;
     }
+    S.exact_extent = exact_extent ? 1u : 0u;
     uint32_t wide_levels = 0;  // wide nodes on the longest way down a BLAS (0: no wide nodes were built)
     uint64_t walk_bytes = 0;   // what the walks read: nodes, wide nodes, triangle vertices, instance records
     size_t n_scene_nodes = 0;  // DevScene::nodes: TLAS + its leaf copies + every BLAS

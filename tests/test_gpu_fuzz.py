@@ -128,6 +128,43 @@ def test_random_scene_matches_oracle(gpu_ctx, seed):
         assert (img.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all(), (seed, integrator)
 
 
+def test_a_raised_extent_reaches_a_mirrored_quad_hit(gpu_ctx):
+    """Seed 211699 of tools/soak_fuzz.py (round 4; rounds 1-3 differ on it too).  `ray.set_extent(isect.ray_t)` of tlas/src/bvh.rs:84-88
+    takes the LEFT subtree's result, not the best hit so far: a mesh may return a hit beyond the extent it was given (blas.rs:468) and
+    the extent then rises.  Boxes the best hit would have pruned are entered; what they hold loses at the compare — unless the shape
+    reports hits outside its own box, as a ParallelQuad does in its mirrored quadrants (D1).  This ray (a zero direction component;
+    bounce 2 -> 3 of film pixel (18, 43), sample 1) finds a sphere at t = 0.5716, then a mesh returns 0.93 and lifts the extent over the
+    quad's box (entered at 0.7666), whose mirrored hit at t = 0.3496 wins.  Scenes with a ParallelQuad next to a mesh therefore walk
+    with the extent followed to the letter (PBRS_FEAT_EXTENT, bit 8 of kernel_features_extend)."""
+    seed = 211699
+    sb = random_scene(seed)
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    o = np.array([[1076550976, 1070745188, 3218686800]], dtype=np.uint32).view(np.float32)
+    d = np.array([[0, 3212667273, 1041316617]], dtype=np.uint32).view(np.float32)
+    kinds = {sb.build().shapes[i].kind for i in range(sb.build().n_shapes)}
+    assert spec.SHAPE_QUAD in kinds
+    for tmax in (np.inf, 1e30, 0.6):
+        t = np.array([tmax], dtype=np.float32)
+        h_ref, occ_ref, st = osc.intersect(o, d, t)
+        h_gpu, occ_gpu = gpu_ctx.intersect(o, d, t)
+        assert not st["tie_mask"].any()
+        assert h_ref["inst"][0] == 2 and h_ref["t"].view(np.uint32)[0] == np.float32(0.34959823).view(np.uint32)  # the quad, behind the raised extent
+        assert h_gpu["inst"][0] == h_ref["inst"][0] and h_gpu["t"].view(np.uint32)[0] == h_ref["t"].view(np.uint32)[0]
+        assert (occ_ref == occ_gpu).all()
+    for integrator, depth in (("path", 7), ("direct", 3)):
+        ref, ost = osc.render(2, 2, depth, 11 + seed, integrator=integrator)
+        for counters in (True, False):
+            img, st = gpu_ctx.render(2, 2, depth, 11 + seed, integrator=integrator, counters=counters)
+            assert st["kernel_features_extend"] & 256, st["kernel_features_extend"]
+            assert ost["tlas_ties"] == 0
+            if counters:
+                assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+                assert st["instances"] + st["shadow_instances"] == ost["instances"]  # what the boxes decide, closest and any-hit walks together
+            nan = np.isnan(ref)
+            assert (nan == np.isnan(img)).all() and (img.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all(), (integrator, counters)
+
+
 def test_random_scenes_contain_parallel_quads():
     kinds = set()
     for seed in range(48):
