@@ -12,7 +12,10 @@ from pbrs_amd.spec import SceneBuilder, Transform, deg
 pytestmark = pytest.mark.gpu
 
 
-def random_scene(seed):
+def random_scene(seed, quads=True):
+    """`quads=False`: the same scene with a disk in the plane of every ParallelQuad (same draws, so everything else stays what it was).  A
+    scene with a ParallelQuad next to a mesh renders through the closest-hit walk that follows the reference's extent to the letter
+    (PBRS_FEAT_EXTENT); its twin without quads goes through the kernels every benchmark scene takes."""
     rs = np.random.RandomState(1000 + seed)
     sb = SceneBuilder()
     u = rs.uniform
@@ -64,7 +67,11 @@ def random_scene(seed):
             a = a / np.linalg.norm(a) * u(0.6, 1.4)
             b = np.cross(a, rs.standard_normal(3))
             b = b / np.linalg.norm(b) * u(0.6, 1.4)
-            shape = sb.quad((0.0, 0.0, 0.0), tuple(float(x) for x in a), tuple(float(x) for x in b))
+            if quads:
+                shape = sb.quad((0.0, 0.0, 0.0), tuple(float(x) for x in a), tuple(float(x) for x in b))
+            else:
+                nrm = np.cross(a, b)
+                shape = sb.disk((0.0, 0.0, 0.0), tuple(float(x) for x in nrm / np.linalg.norm(nrm)), tuple(float(x) for x in a))
         elif kind == 0:
             shape = sb.sphere((0, 0, 0), float(u(0.4, 1.1)))
         elif kind == 1:
@@ -123,6 +130,34 @@ def test_random_scene_matches_oracle(gpu_ctx, seed):
             continue
         assert st["closest_rays"] == ost["closest_rays"] and st["shadow_rays"] == ost["shadow_rays"], (seed, integrator)
         assert st["invalid_samples"] == ost["nonfinite_samples"], (seed, integrator)  # samples whose radiance is not finite
+        nan = np.isnan(ref)
+        assert (nan == np.isnan(img)).all(), (seed, integrator)
+        assert (img.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all(), (seed, integrator)
+
+
+def takes_the_exact_extent_walk(sb):
+    built = sb.build()
+    kinds = {built.shapes[built.instances[i].shape].kind for i in range(built.n_instances)}
+    return spec.SHAPE_QUAD in kinds and spec.SHAPE_MESH in kinds
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_scene_without_parallel_quads_matches_oracle(gpu_ctx, seed):
+    """Two thirds of the randomised scenes hold a ParallelQuad next to a mesh and render through the exact-extent walk; their twins with
+    disks for quads take the product's regular kernels (scanned TLAS, scene in LDS) with everything else unchanged."""
+    if not takes_the_exact_extent_walk(random_scene(seed)):
+        pytest.skip("no ParallelQuad in this scene: test_random_scene_matches_oracle ran it through the regular kernels")
+    sb = random_scene(seed, quads=False)
+    assert not takes_the_exact_extent_walk(sb)
+    osc = OracleScene(sb)
+    gpu_ctx.upload(pbrs_amd.HostScene(sb))
+    for integrator, depth in (("path", 7), ("direct", 3)):
+        ref, ost = osc.render(2, 2, depth, 11 + seed, integrator=integrator)
+        img, st = gpu_ctx.render(2, 2, depth, 11 + seed, integrator=integrator, counters=False)
+        assert not st["kernel_features_extend"] & 256
+        if ost["tlas_ties"]:
+            SKIPPED_FOR_TIES.append((seed, integrator + " (no quads)"))
+            continue
         nan = np.isnan(ref)
         assert (nan == np.isnan(img)).all(), (seed, integrator)
         assert (img.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all(), (seed, integrator)

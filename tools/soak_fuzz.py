@@ -1,8 +1,8 @@
 """Developer tool (GPU box): the randomised-scene parity tests of tests/test_gpu_fuzz.py over a range of seeds far beyond the ones
-the suite runs: images of both integrators (also with two objects re-covered by Fourier BSDFs) and hit records / occlusion ray by
-ray, GPU vs oracle, bit for bit.
+the suite runs: images of both integrators (also with two objects re-covered by Fourier BSDFs; scenes that hold a ParallelQuad next to a mesh also as
+their twin with disks for quads, which takes the regular kernels) and hit records / occlusion ray by ray, GPU vs oracle, bit for bit.
 
-usage: python tools/soak_fuzz.py [first_seed [end_seed]] [--budget SECONDS]     (default 48 3000; about 40 seeds per second)
+usage: python tools/soak_fuzz.py [first_seed [end_seed]] [--budget SECONDS]     (default 48 3000; about 15 seeds per second)
 
 The run ends ITSELF: at end_seed or when the wall-clock budget is spent (default 240 s), whichever comes first, and always prints
 its verdict line `seeds a .. b failures: [...]` and exits 0 (no failure) or 1 — size the budget to the GPU minutes at hand instead of
@@ -34,6 +34,8 @@ while seed < end and time.perf_counter() - t0 < budget:
         F.test_random_scene_rays_match_oracle(ctx, seed)
         F.test_random_scene_matches_oracle(ctx, seed)
         F.test_random_scene_with_fourier_materials_matches_oracle(ctx, seed)
+        if F.takes_the_exact_extent_walk(F.random_scene(seed)):  # its twin without ParallelQuads: through the regular kernels
+            F.test_random_scene_without_parallel_quads_matches_oracle(ctx, seed)
     except AssertionError as e:
         bad.append((seed, str(e)[:100]))
     if seed % 256 == 0:
