@@ -325,7 +325,7 @@ class Workload:
             "kernel_features": {"extend": int(per_frame[-1]["kernel_features_extend"]) if per_frame[-1] else None,
                                 "shadow": int(per_frame[-1]["kernel_features_shadow"]) if per_frame[-1] else None,
                                 "bits": "1 analytic shapes, 2 shading check, 4 scanned TLAS, 8 several node steps per round, 16 four-wide nodes, "
-                                        "32 full further node steps (scene outside the guarded range of the division-free box test), 64 scene arrays in LDS, 128 TLAS in LDS"},
+                                        "32 full further node steps (scene outside the guarded range of the division-free box test), 64 scene arrays in LDS, 128 TLAS in LDS, 256 (extend) the TLAS extent followed to the letter (a ParallelQuad next to a mesh)"},
             "per_rank": per_rank,
             "band_imbalance": max(r["rows"] for r in per_rank) / (sum(r["rows"] for r in per_rank) / len(per_rank)),
             "roofline_inconsistent": inconsistent or False,
