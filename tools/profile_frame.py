@@ -38,7 +38,9 @@ def main():
                       "samples_per_pass": -(-spp // st["passes"]), "frames": a.frames + (0 if a.no_warm else 1),
                       "stages_ms": {k: v for k, v in st.items() if k.startswith("ms_")}, "scene_bytes": hs.nbytes,
                       # what the counters of this run were measured on (bench.py quotes them only for the same sources)
-                      "source_hash": roofline.source_hash(), "git_head": os.environ.get("PBRS_GIT_HEAD", "unknown")}))
+                      "source_hash": roofline.source_hash(),
+                      # no .git travels to the GPU box: the commit is stamped from the builder side (PBRS_GIT_HEAD) or left out
+                      **({"git_head": os.environ["PBRS_GIT_HEAD"]} if os.environ.get("PBRS_GIT_HEAD") else {})}))
     ctx.close()
 
 

@@ -43,7 +43,8 @@ tatd = parse(sys.argv[8]) if len(sys.argv) > 8 else {}
 sq2 = parse(sys.argv[9]) if len(sys.argv) > 9 else {}  # the second SQ pass: scalar, memory and LDS instruction counts
 n_pixels = geo["pixels"]
 n_slots = n_pixels * geo["samples_per_pass"]
-res = {"unit": "bytes per launch", "geometry": geo, "source_hash": geo.get("source_hash"), "git_head": geo.get("git_head"),
+res = {"unit": "bytes per launch", "geometry": geo, "source_hash": geo.get("source_hash"),
+       **({"git_head": geo["git_head"]} if geo.get("git_head") else {}),
        "note": "l2_fabric_* = bytes of the L2's memory-side requests (FETCH_SIZE / WRITE_SIZE / TCC_EA0_*): they INCLUDE Infinity-Cache "
                "hits, so for a scene that fits the 256 MiB Infinity Cache they are an upper bound of true HBM traffic", "kernels": {}}
 acc = fetch.get("k_accumulate")
