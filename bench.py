@@ -339,7 +339,7 @@ class Workload:
                 "ms_per_launch_serial": dom.get("ms_per_launch_serial"), "frac_serial": dom.get("frac_serial"),
                 "bound_shares": roofline.bound_shares(dom),
                 "valu_issue_frac": dom.get("valu_issue_frac"), "valu_issue_frac_min": dom.get("valu_issue_frac_min"),
-                "valu_issue_frac_nominal": dom.get("valu_issue_frac_nominal"), "valu_32bit_encoding_share": dom.get("valu_32bit_encoding_share"),
+                "valu_issue_upper_price": dom.get("valu_issue_upper_price"), "valu_32bit_encoding_share": dom.get("valu_32bit_encoding_share"),
                 "salu_issue_frac": dom.get("salu_issue_frac"), "valu_lanes_active": dom.get("valu_lanes_active"),
                 "l1_access_frac": dom.get("l1_access_frac"), "l1_accesses_per_launch": dom.get("l1_accesses_per_launch"),
                 "ta_busy_share": dom.get("ta_busy_share"), "td_busy_share": dom.get("td_busy_share"),
@@ -360,7 +360,7 @@ class Workload:
                         "share of the chip's vector issue slots the kernel fills: wave-level VALU instructions per launch (SQ pass in profiles/) priced "
                         "at the kernel's static encoding mix (valu_32bit_encoding_share of them at the 2.7 cycles measured for 32-bit encodings, the "
                         "rest at 4.0: tools/isa_stats.py --json, tools/microbench/issue_rates.hip) over 1024 SIMDs x the live kernel time x 2.4 GHz; "
-                        "valu_issue_frac_nominal / _min = the same count at 4 / at 2.7 cycles each (brackets; the nominal one can pass 1); "
+                        "valu_issue_frac_min = the same count with every instruction at 2.7 cycles, valu_issue_upper_price = with every instruction at 4.0 (an uncalibrated upper price kept for comparison with earlier rounds, NOT a share: it can pass 1); "
                         "salu_issue_frac = scalar instructions x 4.25 cycles over the same slots (they issue beside other waves' vector work)",
             },
             "traversal": trav,

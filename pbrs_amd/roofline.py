@@ -233,7 +233,7 @@ def stage_report(counters, times, scene_nbytes=0, traffic_doc=None, isa_doc=None
             # binds the kernels that HBM does not — a lower bound, the sustained clock being below CLOCK_HZ
             out[stage]["valu_insts_per_launch"] = valu[0]
             out[stage]["valu_lanes_active"] = valu[1]
-            out[stage]["valu_issue_frac_nominal"] = valu[0] * CYCLES_PER_WAVE_VALU / (N_SIMD * sec * CLOCK_HZ)  # every instruction at 4 cycles: may pass 1
+            out[stage]["valu_issue_upper_price"] = valu[0] * CYCLES_PER_WAVE_VALU / (N_SIMD * sec * CLOCK_HZ)  # every instruction at 4 cycles: may pass 1
             # the same count at the cheapest measured issue cost: the true share lies between the two
             out[stage]["valu_issue_frac_min"] = valu[0] * CYCLES_PER_WAVE_VALU_MIN / (N_SIMD * sec * CLOCK_HZ)
             # ... and at the kernel's static encoding mix: the calibrated figure, the one the bound is chosen with

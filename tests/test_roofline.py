@@ -64,8 +64,8 @@ def test_vector_issue_share_from_the_sq_pass():
     rep = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30, traffic_doc=doc)
     e = rep["extend"]
     assert e["valu_insts_per_launch"] == 1.2e6 and e["valu_lanes_active"] == 40.0
-    assert e["valu_issue_frac_nominal"] == 1.2e6 * 4 / (1024 * 1.0e-3 * 2.4e9)  # 2.0 ms over 2 launches
-    assert abs(e["valu_issue_frac_min"] - e["valu_issue_frac_nominal"] * 2.7 / 4) < 1e-12  # ... at the cheapest measured issue cost
+    assert e["valu_issue_upper_price"] == 1.2e6 * 4 / (1024 * 1.0e-3 * 2.4e9)  # 2.0 ms over 2 launches
+    assert abs(e["valu_issue_frac_min"] - e["valu_issue_upper_price"] * 2.7 / 4) < 1e-12  # ... at the cheapest measured issue cost
     # no static mix for these sources: the midpoint of the two prices, and the share of 32-bit encodings is reported as unknown
     assert e["valu_32bit_encoding_share"] is None and abs(e["valu_issue_frac"] - 1.2e6 * 3.35 / (1024 * 1.0e-3 * 2.4e9)) < 1e-12
     assert "valu_issue_frac" not in rep["shade"] and "valu_issue_frac" not in rep["shadow"]  # no SQ figures: not reported
@@ -81,7 +81,7 @@ def test_calibrated_issue_share_from_the_static_encoding_mix_and_the_scalar_shar
     e = roofline.stage_report(COUNTS, TIMES, scene_nbytes=1 << 30, traffic_doc=doc, isa_doc=isa)["extend"]
     slots = 1024 * 1.0e-3 * 2.4e9
     assert e["valu_32bit_encoding_share"] == 0.6
-    assert abs(e["valu_issue_frac"] - 6.0e8 * (0.6 * 2.7 + 0.4 * 4.0) / slots) < 1e-12 and e["valu_issue_frac"] < 1.0 <= e["valu_issue_frac_nominal"] * 1.03
+    assert abs(e["valu_issue_frac"] - 6.0e8 * (0.6 * 2.7 + 0.4 * 4.0) / slots) < 1e-12 and e["valu_issue_frac"] < 1.0 <= e["valu_issue_upper_price"] * 1.03
     assert abs(e["salu_issue_frac"] - 2.0e8 * 4.25 / slots) < 1e-12
     shares = roofline.bound_shares(e)
     assert set(shares) == {"hbm", "valu_issue", "salu_issue", "l1_access", "td_busy"} and all(0.0 <= v <= 1.0 for v in shares.values())
