@@ -275,9 +275,11 @@ class Workload:
             elif geo.get("passes") not in (None, cst["passes"]):
                 traffic_doc, traffic_src = None, f"{traffic_src} ignored: measured at {geo['passes']} passes per frame, this run has {cst['passes']}"
             # ... and when the counters were measured on the kernels being timed: the file carries a hash of the sources
-            elif traffic_doc.get("source_hash") != roofline.source_hash():
+            elif not roofline.counters_apply(traffic_doc)[0]:
                 traffic_doc, traffic_src = None, (f"{traffic_src} ignored: measured on sources {traffic_doc.get('source_hash')} "
                                                   f"(git {traffic_doc.get('git_head')}), this run is built from {roofline.source_hash()}")
+            elif traffic_doc.get("source_hash") != roofline.source_hash():
+                traffic_src = f"{traffic_src} ({roofline.counters_apply(traffic_doc)[1]})"
         isa_doc = None
         ipath = os.path.join(ROOT, "profiles", "latest_isa_mix.json")
         if os.path.exists(ipath):

@@ -120,6 +120,29 @@ struct FourierNbrs {
             }
         return acc;
     }
+    // the same sums for several channels of one term in one pass over the neighbours: per channel the additions of coef_oi in
+    // their order (the series lengths and offsets are fetched once instead of once per channel)
+    template <bool Y>
+    PD void coef_oi_yrb(uint32_t k, float& cy, float& cr, float& cb) const {
+        float ay = 0.0f, ar = 0.0f, ab = 0.0f;
+#pragma unroll
+        for (int b_ = 0; b_ < 4; ++b_)
+#pragma unroll
+            for (int a_ = 0; a_ < 4; ++a_) {
+                const float w = weight(a_, b_);
+                if (w != 0.0f && inside(a_, b_)) {
+                    const uint32_t index = (uint32_t)(offset_o + b_) * n_mu + (uint32_t)(offset_i + a_);
+                    const uint32_t m = m_lookup[index];
+                    if (k < m) {
+                        const float* t = a + (a_offset[index] + k);
+                        if (Y) ay += w * t[0];
+                        ar += w * t[m];
+                        ab += w * t[2u * m];
+                    }
+                }
+            }
+        cy = ay, cr = ar, cb = ab;
+    }
     // ak[k] of prob (:456-468): neighbours of mu_i outside, of mu_o inside; luminance only
     PD float coef_io(uint32_t k) const {
         float acc = 0.0f;
@@ -158,6 +181,23 @@ PD float fourier_sum(Coef coef, uint32_t n, float cos_phi) {
     }
     return (float)sum;
 }
+// fourier_sum of the red and blue series (and the luminance series where Y) of one direction pair in one loop: the cosines
+// of the three calls are the same numbers, each sum takes its terms in the order of its own call
+template <bool Y>
+PD void fourier_sum_yrb(const FourierNbrs& N, uint32_t n, float cos_phi, float& y, float& r, float& b) {
+    double prev = (double)cos_phi, cur = 1.0, sy = 0.0, sr = 0.0, sb = 0.0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const double next = 2.0 * (double)cos_phi * cur - prev;
+        float cy, cr, cb;
+        N.template coef_oi_yrb<Y>(k, cy, cr, cb);
+        if (Y) sy += (double)cy * cur;
+        sr += (double)cr * cur;
+        sb += (double)cb * cur;
+        prev = cur;
+        cur = next;
+    }
+    y = (float)sy, r = (float)sr, b = (float)sb;
+}
 PD float cos_dphi(f3 a, f3 b) {  // bxdf.rs:96-107
     const float res = (a.x * b.x + a.y * b.y) / pn_sqrt((a.x * a.x + a.y * a.y) * (b.x * b.x + b.y * b.y));
     return pn_isfinite(res) ? res : 0.0f;
@@ -169,11 +209,11 @@ PD f3 fourier_eval(const FourierView& V, const pbrs_fourier_table& T, f3 wo, f3 
     FourierNbrs N;
     if (!fourier_nbrs(V, T, mu_i, mu_o, N)) return gray(0.0f);
     const uint32_t m_max = N.order();
-    const float y = pn_max(fourier_sum([&](uint32_t k) { return N.coef_oi(0u, k); }, m_max, cos_phi), 0.0f);
     const float scale = pn_abs(mu_i) == 0.0f ? 0.0f : 1.0f / pn_abs(mu_i);
-    if (T.n_channels == 1u) return gray(y * scale);
-    const float r = fourier_sum([&](uint32_t k) { return N.coef_oi(1u, k); }, m_max, cos_phi);
-    const float b = fourier_sum([&](uint32_t k) { return N.coef_oi(2u, k); }, m_max, cos_phi);
+    if (T.n_channels == 1u) return gray(pn_max(fourier_sum([&](uint32_t k) { return N.coef_oi(0u, k); }, m_max, cos_phi), 0.0f) * scale);
+    float y, r, b;
+    fourier_sum_yrb<true>(N, m_max, cos_phi, y, r, b);
+    y = pn_max(y, 0.0f);
     const float g = 1.39829f * y - 0.100913f * b - 0.297375f * r;
     const f3 c = mk3(r, g, b) * scale;
     return mk3(pn_clamp(c.x, 0.0f, 1.0f), pn_clamp(c.y, 0.0f, 1.0f), pn_clamp(c.z, 0.0f, 1.0f));
@@ -331,8 +371,8 @@ PD void fourier_sample(const FourierView& V, const pbrs_fourier_table& T, f3 wo,
     if (T.n_channels == 1u) {
         f = gray(y * scale);
     } else {
-        const float r = fourier_sum([&](uint32_t k) { return N.coef_oi(1u, k); }, m_max, cos_phi);
-        const float b = fourier_sum([&](uint32_t k) { return N.coef_oi(2u, k); }, m_max, cos_phi);
+        float y_unused, r, b;
+        fourier_sum_yrb<false>(N, m_max, cos_phi, y_unused, r, b);
         const float g = 1.39829f * y - 0.100913f * b - 0.297375f * r;
         f = mk3(r * scale, g * scale, b * scale);
     }

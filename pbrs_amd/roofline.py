@@ -292,6 +292,22 @@ def bound_of(stage_row):
     return max(bound_shares(stage_row).items(), key=lambda kv: kv[1])[0]
 
 
+def counters_apply(traffic_doc, current=None):
+    """Whether a counter file speaks about the kernels of the sources in the tree: measured on these very sources
+    (`source_hash`), or on sources whose kernels NAMED IN THE FILE compile to the same instructions and resource
+    directives — an entry of `same_isa_as_measured` (written on the builder side from tools/isa_same_kernels.py's
+    comparison of the two device assemblies, its log under profiles/) that names the tree's hash and lists the kernels
+    that do differ.  Returns (ok, how)."""
+    current = current or source_hash()
+    if traffic_doc.get("source_hash") == current:
+        return True, "measured on these sources"
+    for e in traffic_doc.get("same_isa_as_measured", []):
+        if e.get("source_hash") == current and not (set(e.get("differing_kernels", [])) & set(traffic_doc.get("kernels", {}))):
+            return True, (f"measured on sources {traffic_doc.get('source_hash')}; every kernel of the file compiles to the same "
+                          f"instructions from {current} ({e.get('log')})")
+    return False, None
+
+
 def source_hash(root=None):
     """sha256 over the sources the kernels are built from (pbrs_amd/csrc/**, include/*.h): stamps a traffic file
     (tools/profile_frame.py -> tools/traffic_from_pmc.py) so that bench.py can tell whether the offline counters it

@@ -156,3 +156,24 @@ def test_offline_counter_shares_divide_by_the_exclusive_time():
     for key in ("valu_issue_frac", "salu_issue_frac", "l1_access_frac", "frac_measured"):
         assert abs(a[key] - b[key]) < 1e-12, key
     assert abs(b["frac"] * 2.5 - a["frac"]) < 1e-12 and abs(b["frac_serial"] - a["frac"]) < 1e-12
+
+
+def test_counter_files_carry_over_only_to_sources_with_the_same_kernels():
+    doc = {"source_hash": "abc", "kernels": {"k_extend<false, 13u>": {}, "k_shade<0u, false, 35u>": {}}}
+    assert roofline.counters_apply(doc, "abc")[0] and not roofline.counters_apply(doc, "xyz")[0]
+    doc["same_isa_as_measured"] = [{"source_hash": "xyz", "differing_kernels": ["k_shade<0u, false, 24u>"], "log": "profiles/x.log"}]
+    ok, how = roofline.counters_apply(doc, "xyz")
+    assert ok and "abc" in how and "profiles/x.log" in how and not roofline.counters_apply(doc, "other")[0]
+    # a file that quotes a kernel whose instructions changed does not carry over
+    doc["same_isa_as_measured"][0]["differing_kernels"].append("k_shade<0u, false, 35u>")
+    assert not roofline.counters_apply(doc, "xyz")[0]
+
+
+def test_the_committed_counter_files_apply_to_the_sources_in_the_tree():
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(roofline.__file__)))
+    for p in glob.glob(os.path.join(root, "profiles", "latest_traffic_*.json")):
+        with open(p) as f:
+            assert roofline.counters_apply(json.load(f))[0], p
